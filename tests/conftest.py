@@ -1,0 +1,50 @@
+"""pytest configuration: GPU marker, repo paths and the scene-asset helper."""
+import hashlib
+import lzma
+import os
+import sys
+import tempfile
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+# sha256 of the reference's P3D_Scenes/*.p3f input assets (see tests/golden/README.md)
+SCENE_SHA256 = {
+    "balls_box": "41e50662b9b735119db633ce343c59c1b2073b517fe5826f212035786b171c68",
+    "balls_low": "1cab9d2ef91126a415d4dbb875787eebc6f71b1c02e67cf17d2b8fff968a2cd1",
+    "balls_medium": "fe5bd053609292997fd7ef9e808a4f979cdbee6ee8a12a6255ce596b84beac54",
+    "dof": "339edf0b7d0c4e4fe0bf42ab624d35d142b0e29fea9583388297c9a78abba372",
+    "dragon": "7ac9775563238c5302c8fac4bf1e6f1d823192a3bcf4922cb4d391bc1a50b695",
+    "mount_high": "0cf73c05202e36dae02f077abc697df40307452143786ab2da4a407dc26f1524",
+    "mount_low": "97744fbe09f83b9182b56680ff96ca4c1de89f34afb09f2cfb314d13d7357146",
+}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def scene_path(name):
+    """Unpack tests/golden/scenes/<name>.p3f.xz into a per-user cache and return the path."""
+    cache = os.path.join(tempfile.gettempdir(), "p3d_scene_cache_%d" % os.getuid())
+    os.makedirs(cache, exist_ok=True)
+    out = os.path.join(cache, name + ".p3f")
+    if not os.path.exists(out):
+        with lzma.open(os.path.join(GOLDEN, "scenes", name + ".p3f.xz"), "rb") as f:
+            data = f.read()
+        assert hashlib.sha256(data).hexdigest() == SCENE_SHA256[name], name
+        tmp = out + ".%d.tmp" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, out)
+    return out
+
+
+@pytest.fixture(scope="session")
+def scenes():
+    return scene_path
