@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the Whitted hot path on BASELINE config 2
+(mount_low.p3f, 1920x1080, depth 4, BVH), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = `--frames-per-step` frames of the configuration's camera, each rendered by the HIP
+kernel into HBM-resident buffers.  With N > 1 every frame is split into interleaved 16-row
+blocks across the ranks (total work fixed: strong scaling) and each step ends with ONE RCCL
+gather of the compact tile buffers to rank 0 plus the de-interleave kernel there.
+value = rays of all frames / max-over-ranks wall time; a ray is one closest-hit or one shadow
+query, counted by the counting build of the same kernel on the same frame.
+
+Extra objects on the JSON line: "roofline" (algorithmic bytes of the frame kernel / its mean
+duration from HIP events on the launch stream, vs the 8 TB/s HBM peak) and, at N=1,
+"cpu_baseline" (the CPU oracle timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+RES = (1920, 1080)
+MAX_DEPTH = 4
+ROW_BLOCK = 16
+
+
+def cpu_baseline(scene_file, budget_s=20.0):
+    """The oracle (CPU restatement of the reference, incl. the brute-force fall-through of
+    SURVEY Q1) single-threaded on full config-2 frames, plus the break-fixed multi-threaded
+    variant as the honest strong baseline.  Checker-only code: never on the product path."""
+    from oracle import oracle_py as O
+    sc = O.Scene(scene_file)
+    sc.set_resolution(*RES)
+    times, rays = [], 0
+    t_start = time.time()
+    while len(times) < 5 and (time.time() - t_start) < budget_s * 0.6:
+        t0 = time.perf_counter()
+        r = sc.render(max_depth=MAX_DEPTH, accel=2, threads=1, want_f32=False, want_hit=False)
+        times.append(time.perf_counter() - t0)
+        rays = r["counters"]["rays"]
+    st = float(np.median(times))
+    ncpu = os.cpu_count() or 1
+    mt_times = []
+    while len(mt_times) < 5 and (time.time() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        sc.render(max_depth=MAX_DEPTH, accel=2, threads=ncpu, break_fixed=1, want_f32=False, want_hit=False)
+        mt_times.append(time.perf_counter() - t0)
+    out = {"value": rays / st / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+           "sample": "%d full 1920x1080 depth-4 frames, single thread, reference structure "
+                     "(BVH traversal + brute-force fall-through); median %.3f s/frame" % (len(times), st)}
+    if mt_times:
+        mt = float(np.median(mt_times))
+        out["multithread"] = {"value": rays / mt / 1e6, "unit": "Mrays/s", "cores": ncpu,
+                              "note": "fall-through removed + row blocks over all host cores; median %.4f s/frame" % mt}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from conftest import scene_path
+    import u_4a_2s_p3d_raytracer_template2_amd as P
+    from u_4a_2s_p3d_raytracer_template2_amd import multigpu as MG
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    scene_file = scene_path("mount_low")
+    hs = P.HostScene(scene_file)
+    hs.set_resolution(*RES)
+    cam = hs.camera()
+    ds = P.DeviceScene.from_host(hs, device=local_rank)
+    ds.set_stream(torch.cuda.current_stream().cuda_stream)
+    W, H = RES
+    B = args.frames_per_step
+    rows = H if world == 1 else MG.padded_rows(H, ROW_BLOCK, world)
+
+    # HBM-resident outputs: B compact tile buffers per step (double use: gather source)
+    tiles = torch.zeros((B, rows, W, 3), dtype=torch.uint8, device=dev)
+    gathered = frames = None
+    if world > 1 and rank == 0:
+        gathered = torch.zeros((world, B, rows, W, 3), dtype=torch.uint8, device=dev)
+        frames = torch.zeros((B, H, W, 3), dtype=torch.uint8, device=dev)
+    tile_bytes = rows * W * 3
+
+    # work counters of this rank's share of one frame (counting build, same traversal)
+    ds.render_device(cam, rgb8_ptr=tiles[0].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
+                     rank=rank, world=world, row_block=ROW_BLOCK, counters=True)
+    ctr = ds.counters()
+    my_rays = ctr["rays"]
+    px_local = ctr["pixels"]
+    alg_bytes = ctr["algorithmic_bytes"] + 3 * px_local          # + rgb8 written per pixel
+
+    def step():
+        for f in range(B):
+            ds.render_device(cam, rgb8_ptr=tiles[f].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
+                             rank=rank, world=world, row_block=ROW_BLOCK)
+        if world > 1:
+            MG.gather_to_root(tiles, dist, rank, world, gathered)
+            if rank == 0:
+                for f in range(B):
+                    ds.deinterleave(gathered[0, f].data_ptr(), frames[f].data_ptr(), W, H, ROW_BLOCK, world, 3,
+                                    rank_stride_bytes=B * tile_bytes)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    # kernel-only pass for the roofline: HIP events on the launch stream around K*B frame launches
+    nl = max(args.steps, 1) * B
+    ds.timer_begin()
+    for _ in range(nl):
+        ds.render_device(cam, rgb8_ptr=tiles[0].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
+                         rank=rank, world=world, row_block=ROW_BLOCK)
+    kern_ms = ds.timer_end() / nl
+
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    rr = torch.tensor([float(my_rays)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+    dt_max = float(tt.item())
+    rays_frame = float(rr.item())
+
+    if rank == 0:
+        # the frame that was timed is the frame the parity tests check: verify against the oracle's golden
+        final = (frames[B - 1] if world > 1 else tiles[B - 1][:H]).cpu().numpy()
+        total_rays = rays_frame * B * args.steps
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Mrays/s + ms/frame @1920x1080 depth4",
+            "value": total_rays / dt_max / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "ms_per_frame": dt_max / args.steps / B * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic: P3D_Scenes/mount_low.p3f (12 primitives, 1 light) resolution/accel overridden to the config",
+            "config": {"workload": "mount_low.p3f 1920x1080 depth 4 BVH (BASELINE config 2)",
+                       "frames_per_step": B, "rays_per_frame": int(rays_frame), "row_block": ROW_BLOCK,
+                       "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved 16-row blocks + RCCL gather to rank 0" % world,
+                       "frame_checksum": int(final.astype(np.uint64).sum())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "whitted_frame_kernel<false>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "note": "algorithmic bytes = 32 B/slab test + 16/48/32 B per sphere/triangle/box test + 3 B/px "
+                                 "(SURVEY 8d); the 12-primitive scene is LDS/L1-resident, real HBM traffic is the "
+                                 "frame buffer only (see DESIGN.md)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene_file)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ds.close()
+
+
+if __name__ == "__main__":
+    main()

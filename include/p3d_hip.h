@@ -1,0 +1,192 @@
+/*
+ * p3d_hip.h -- C-ABI of the MI355X-native Whitted renderer (libp3d_hip.so).
+ *
+ * The reference (P3D_RayTracer_Template2, RT/ = /root/reference/P3D_RayTracer_Template2/)
+ * has no plugin/FFI surface: its hot path is one function, renderScene() (RT/main.cpp:732),
+ * reached through globals.  This header is the boundary a maintainer binds instead of that
+ * loop: plain pointers and sizes only, no C++ or torch types.  Each entry point names the
+ * reference code it replaces.  INTEGRATION.md shows the reference-side call sites.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative p3d_status; p3d_last_error()
+ *     describes the failure (the reference prints and exit()s, RT/main.cpp:827; the library
+ *     never exits the process);
+ *   - the caller owns every host buffer; the library owns device memory behind p3d_scene;
+ *   - a p3d_scene is bound to one HIP device and must not be used from two threads at once;
+ *   - render calls are asynchronous on the scene's HIP stream; p3d_sync() or a host-memory
+ *     download waits for them.
+ */
+#ifndef P3D_HIP_H
+#define P3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P3D_ABI_VERSION 1
+
+typedef enum p3d_status {
+    P3D_OK = 0,
+    P3D_ERR_ARG = -1,        /* bad argument / inconsistent sizes                       */
+    P3D_ERR_HIP = -2,        /* a HIP runtime call failed                               */
+    P3D_ERR_NO_DEVICE = -3,  /* no usable gfx950 device                                 */
+    P3D_ERR_LIMIT = -4,      /* scene exceeds a kernel limit (LDS stack, depth)         */
+    P3D_ERR_STATE = -5       /* call made in the wrong state                            */
+} p3d_status;
+
+/* primitive kinds, RT/scene.h:67-145 */
+enum { P3D_SPHERE = 0, P3D_TRIANGLE = 1, P3D_BOX = 2, P3D_PLANE = 3 };
+
+/* accelerator enum of RT/scene.h:18; selects the SHADOW-RAY semantics:
+ * NONE = un-normalised direction, no distance bound; GRID/BVH = normalised, t < |L|.
+ * Closest hits are always "nearest, lowest scene index on ties" (SURVEY Q1). */
+enum { P3D_ACCEL_NONE = 0, P3D_ACCEL_GRID = 1, P3D_ACCEL_BVH = 2 };
+
+/* Flattened scene in SCENE ORDER (the order Scene::addObject saw, RT/scene.cpp:302).
+ * prim_data holds 12 floats per primitive:
+ *   sphere   c.x c.y c.z r                    (RT/scene.h:116-131)
+ *   triangle P0 P1 P2                         (RT/scene.cpp:10)
+ *   box      min max                          (RT/scene.cpp:188)
+ *   plane    PN.x PN.y PN.z D                 (unit normal and offset, RT/scene.cpp:95-115)
+ * materials hold 12 floats: diffuse rgb, Kd, specular rgb, Ks, shine, T, ior, reflection
+ * (RT/scene.h:23-55; reflection == Ks for loader-made materials, RT/scene.h:31).
+ * lights hold 6 floats: position xyz, colour rgb (RT/scene.h:57-65). */
+typedef struct p3d_scene_desc {
+    uint32_t        n_prims;
+    const uint32_t* prim_type;
+    const float*    prim_data;
+    const uint32_t* prim_material;
+    uint32_t        n_materials;
+    const float*    materials;
+    uint32_t        n_lights;
+    const float*    lights;
+    float           background[3];   /* Scene::GetBackgroundColor, RT/scene.h:155 */
+} p3d_scene_desc;
+
+/* BVH construction knobs (replaces BVH::Build, RT/bvh.cpp:28-158; the tree need not match
+ * the reference's because its closest-hit result is discarded). */
+typedef struct p3d_build_opts {
+    uint32_t leaf_max;        /* max primitives per leaf, 1..8; 0 = default (4)          */
+    uint32_t sah_bins;        /* 0 = default (16)                                       */
+    uint32_t reserved;        /* must be 0                                              */
+} p3d_build_opts;
+
+/* The values Camera::Camera derives (RT/camera.h:35-73); PrimaryRay (RT/camera.h:91-127)
+ * is evaluated on the device from these. */
+typedef struct p3d_camera {
+    float   eye[3], u[3], v[3], n[3];
+    float   w, h, plane_dist;
+    float   aperture;        /* lens aperture in world units, RT/camera.h:65            */
+    float   focal_ratio;
+    int32_t res_x, res_y;
+} p3d_camera;
+
+typedef struct p3d_render_params {
+    int32_t  max_depth;      /* MAX_DEPTH, RT/main.cpp:34                                */
+    int32_t  accel;          /* P3D_ACCEL_*: shadow-ray semantics, RT/main.cpp:476-510  */
+    int32_t  spp;            /* 0 = Whitted one sample at pixel centre; n = n*n samples
+                                with thin lens, summed and divided by 16   */
+    const float* samples;    /* spp>0: HOST array [res_y][res_x][spp*spp][4] =
+                                pixel sample x, y, lens x, lens y in reference RNG order
+                                (RT/main.cpp:776-801); uploaded by the call              */
+    /* image-space sharding: this device renders the row blocks b with
+     * b % world == rank, row_block rows each, into a COMPACT buffer of
+     * p3d_local_rows() rows.  world = 1 renders the whole frame. */
+    int32_t  row_block;      /* rows per block, multiple of 16; 0 = default (16)         */
+    int32_t  rank, world;
+    uint32_t flags;          /* P3D_FLAG_*                                              */
+} p3d_render_params;
+
+#define P3D_FLAG_COUNTERS 1u  /* accumulate p3d_counters on the device (slower kernel)   */
+
+/* Work counters in the unit of SURVEY §8d (one ray = one closest-hit or shadow query). */
+typedef struct p3d_counters {
+    uint64_t closest_queries;
+    uint64_t shadow_queries;
+    uint64_t box_tests;      /* node AABB slab tests (32 algorithmic bytes each)         */
+    uint64_t sphere_tests;   /* 16 B each                                               */
+    uint64_t tri_tests;      /* 48 B each                                               */
+    uint64_t aabox_tests;    /* 32 B each                                               */
+    uint64_t plane_tests;    /* 16 B each                                               */
+    uint64_t pixels;
+} p3d_counters;
+
+/* Output planes. Pointers may be NULL. memory: 0 = host pointers (the call copies and
+ * returns after the frame is complete), 1 = device pointers on the scene's device (the
+ * call only enqueues the kernel). A plane holds res_y rows when world == 1 and
+ * p3d_local_rows() rows (this rank's compact shard) when world > 1. Layout follows img_Data / colors of RT/main.cpp:70-76:
+ * row 0 is the BOTTOM row; rgb8 is 3 bytes per pixel, rgb32f 3 floats per pixel (clamped
+ * colour before quantisation), hit_id the scene index of the primary hit or -1. */
+typedef struct p3d_outputs {
+    uint8_t* rgb8;
+    float*   rgb32f;
+    int32_t* hit_id;
+    int32_t  memory;
+} p3d_outputs;
+
+typedef struct p3d_scene p3d_scene;
+
+typedef struct p3d_scene_stats {
+    uint32_t n_nodes, n_leaves, max_depth, n_leaf_refs;
+    uint32_t n_spheres, n_triangles, n_boxes, n_planes, n_culled;
+    uint64_t device_bytes;
+    float    sah_cost;
+} p3d_scene_stats;
+
+int         p3d_abi_version(void);
+const char* p3d_last_error(void);
+int         p3d_device_count(int* count);
+
+/* Replaces init_scene()'s accelerator set-up (RT/main.cpp:912-936) and BVH::Build
+ * (RT/bvh.cpp:28): flattens nothing (the caller did), builds the BVH on the host, uploads
+ * scene + BVH to `device`. opts may be NULL. */
+int p3d_scene_create(const p3d_scene_desc* desc, const p3d_build_opts* opts, int device,
+                     p3d_scene** out);
+int p3d_scene_destroy(p3d_scene* scene);
+int p3d_scene_get_stats(const p3d_scene* scene, p3d_scene_stats* out);
+
+/* Rows of the compact per-rank tile buffer: ceil(n_row_blocks / world) * row_block, the
+ * same on every rank so that the gather moves equal-sized buffers (rows past the image are
+ * never written). */
+int p3d_local_rows(int32_t res_y, int32_t row_block, int32_t world);
+
+/* Replaces renderScene() (RT/main.cpp:732-832) incl. Camera::PrimaryRay, rayTracing(),
+ * processLight() and every intercepts() beneath them. */
+int p3d_render(p3d_scene* scene, const p3d_camera* cam, const p3d_render_params* params,
+               const p3d_outputs* out);
+int p3d_sync(p3d_scene* scene);
+/* counters of the most recent render made with P3D_FLAG_COUNTERS (waits for it) */
+int p3d_get_counters(p3d_scene* scene, p3d_counters* out);
+
+/* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the
+ * scene's own stream. */
+int p3d_set_stream(p3d_scene* scene, void* hip_stream);
+
+/* HIP-event bracket on the scene's stream: begin, enqueue renders, end -> elapsed ms of
+ * everything enqueued in between (waits for completion). */
+int p3d_timer_begin(p3d_scene* scene);
+int p3d_timer_end(p3d_scene* scene, float* elapsed_ms);
+
+/* Rank-0 side of the multi-GPU frame: `gathered` points at rank 0's compact
+ * tile buffer (p3d_local_rows() rows); rank r's buffer starts rank_stride_bytes * r further
+ * (0 = buffers back to back). Writes the full bottom-up frame. bytes_per_pixel = 3 (rgb8),
+ * 12 (rgb32f) or 4 (hit_id). Device pointers, enqueued on the scene's stream. */
+int p3d_deinterleave(p3d_scene* scene, const void* gathered, void* frame, int32_t res_x,
+                     int32_t res_y, int32_t row_block, int32_t world, int32_t bytes_per_pixel,
+                     uint64_t rank_stride_bytes);
+
+/* Unit-level probe used by the parity tests: intersect n rays with one primitive each using
+ * the DEVICE intersectors (Sphere/Triangle/aaBox/Plane::intercepts, RT/scene.cpp:55-283).
+ * Host arrays: type[n], prim12[n*12] (plane = PN,D), origin[n*3], dir[n*3] -> hit[n], t[n],
+ * normal[n*3] (getNormal(hit point).normalize()). */
+int p3d_debug_intersect(int device, uint32_t n, const uint32_t* type, const float* prim12,
+                        const float* origin, const float* dir, int32_t* hit, float* t,
+                        float* normal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P3D_HIP_H */

@@ -1,0 +1,11 @@
+"""MI355X-native Whitted renderer for P3D .p3f scenes -- Python harness over the C-ABI.
+
+The product is csrc/ (HIP kernels, C-ABI, C++ host layer).  This package is the thin ctypes
+binding that tests/ and bench.py drive it through; it holds no rendering logic and has no CPU
+fallback: importing `api` without a built libp3d_hip.so raises.
+"""
+from .api import (ACCEL_BVH, ACCEL_GRID, ACCEL_NONE, Counters, DeviceScene, HostScene, P3DError,
+                  build_native, debug_intersect, device_count, host_bvh, lib, local_rows)
+
+__all__ = ["ACCEL_BVH", "ACCEL_GRID", "ACCEL_NONE", "Counters", "DeviceScene", "HostScene", "P3DError",
+           "build_native", "debug_intersect", "device_count", "host_bvh", "lib", "local_rows"]

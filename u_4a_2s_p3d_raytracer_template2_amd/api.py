@@ -1,0 +1,349 @@
+"""ctypes binding of libp3d_hip.so (include/p3d_hip.h + the p3dh_* host shim)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libp3d_hip.so")
+
+ACCEL_NONE, ACCEL_GRID, ACCEL_BVH = 0, 1, 2
+FLAG_COUNTERS = 1
+
+
+class P3DError(RuntimeError):
+    pass
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_prims", C.c_uint32), ("prim_type", C.POINTER(C.c_uint32)),
+                ("prim_data", C.POINTER(C.c_float)), ("prim_material", C.POINTER(C.c_uint32)),
+                ("n_materials", C.c_uint32), ("materials", C.POINTER(C.c_float)),
+                ("n_lights", C.c_uint32), ("lights", C.POINTER(C.c_float)),
+                ("background", C.c_float * 3)]
+
+
+class BuildOpts(C.Structure):
+    _fields_ = [("leaf_max", C.c_uint32), ("sah_bins", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3), ("n", C.c_float * 3),
+                ("w", C.c_float), ("h", C.c_float), ("plane_dist", C.c_float), ("aperture", C.c_float),
+                ("focal_ratio", C.c_float), ("res_x", C.c_int32), ("res_y", C.c_int32)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("max_depth", C.c_int32), ("accel", C.c_int32), ("spp", C.c_int32),
+                ("samples", C.POINTER(C.c_float)), ("row_block", C.c_int32), ("rank", C.c_int32),
+                ("world", C.c_int32), ("flags", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("closest_queries", "shadow_queries", "box_tests", "sphere_tests",
+                                          "tri_tests", "aabox_tests", "plane_tests", "pixels")]
+
+    def as_dict(self):
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_}
+        d["rays"] = d["closest_queries"] + d["shadow_queries"]
+        # SURVEY §8d algorithmic bytes, without the per-pixel output term
+        d["algorithmic_bytes"] = (32 * d["box_tests"] + 16 * d["sphere_tests"] + 48 * d["tri_tests"] +
+                                  32 * d["aabox_tests"] + 16 * d["plane_tests"])
+        return d
+
+
+class Outputs(C.Structure):
+    _fields_ = [("rgb8", C.c_void_p), ("rgb32f", C.c_void_p), ("hit_id", C.c_void_p), ("memory", C.c_int32)]
+
+
+class SceneStats(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("max_depth", C.c_uint32),
+                ("n_leaf_refs", C.c_uint32), ("n_spheres", C.c_uint32), ("n_triangles", C.c_uint32),
+                ("n_boxes", C.c_uint32), ("n_planes", C.c_uint32), ("n_culled", C.c_uint32),
+                ("device_bytes", C.c_uint64), ("sah_cost", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/p3d_hip.h declares (tests check that the library exports them all)
+C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_scene_create",
+                 "p3d_scene_destroy", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
+                 "p3d_get_counters", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end",
+                 "p3d_deinterleave", "p3d_debug_intersect"]
+
+
+def build_native(verbose=False):
+    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc"), "-j4", "all"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  No fallback: a missing extension is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise P3DError("native extension %s is missing: run __graft_entry__.build() "
+                       "(make -C u_4a_2s_p3d_raytracer_template2_amd/csrc)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.p3d_last_error.restype = C.c_char_p
+    L.p3d_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.p3d_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(BuildOpts), C.c_int, C.POINTER(C.c_void_p)]
+    L.p3d_scene_destroy.argtypes = [C.c_void_p]
+    L.p3d_scene_get_stats.argtypes = [C.c_void_p, C.POINTER(SceneStats)]
+    L.p3d_local_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.p3d_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.POINTER(Outputs)]
+    L.p3d_sync.argtypes = [C.c_void_p]
+    L.p3d_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+    L.p3d_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.p3d_timer_begin.argtypes = [C.c_void_p]
+    L.p3d_timer_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.p3d_deinterleave.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_uint64]
+    L.p3d_debug_intersect.argtypes = [C.c_int, C.c_uint32] + [C.c_void_p] * 7
+    # host shim
+    L.p3dh_scene_load.restype = C.c_void_p
+    L.p3dh_scene_load.argtypes = [C.c_char_p]
+    L.p3dh_scene_free.argtypes = [C.c_void_p]
+    L.p3dh_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.p3dh_scene_set_resolution.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.p3dh_scene_set_eye.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    L.p3dh_scene_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+    L.p3dh_scene_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
+    L.p3dh_primary_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.p3dh_generate_samples.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+    L.p3dh_bvh_build.restype = C.c_void_p
+    L.p3dh_bvh_build.argtypes = [C.POINTER(SceneDesc), C.c_uint32]
+    L.p3dh_bvh_free.argtypes = [C.c_void_p]
+    L.p3dh_bvh_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.p3dh_bvh_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise P3DError("%s failed (%d): %s" % (what, rc, lib().p3d_last_error().decode()))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().p3d_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def local_rows(res_y, row_block=16, world=1):
+    return lib().p3d_local_rows(res_y, row_block, world)
+
+
+class HostScene:
+    """Scene loaded by the C++ host layer (Scene::load_p3f mirror) and flattened for the C-ABI."""
+
+    def __init__(self, path):
+        self.h = lib().p3dh_scene_load(os.fsencode(path))
+        if not self.h:
+            raise P3DError("cannot load scene %s" % path)
+        self._refresh()
+
+    def _refresh(self):
+        out = (C.c_int32 * 8)()
+        lib().p3dh_scene_info(self.h, out)
+        (self.n_prims, self.n_lights, self.n_materials, self.res_x, self.res_y, self.accel, self.spp,
+         self.parse_ok) = [int(v) for v in out]
+
+    def close(self):
+        if self.h:
+            lib().p3dh_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_resolution(self, w, h):
+        lib().p3dh_scene_set_resolution(self.h, int(w), int(h))
+        self._refresh()
+
+    def set_eye(self, x, y, z):
+        lib().p3dh_scene_set_eye(self.h, float(x), float(y), float(z))
+
+    def desc(self):
+        d = SceneDesc()
+        lib().p3dh_scene_desc(self.h, C.byref(d))
+        return d
+
+    def camera(self):
+        c = Camera()
+        lib().p3dh_scene_camera(self.h, C.byref(c))
+        return c
+
+    def primary_ray(self, px, py):
+        o = (C.c_float * 3)()
+        d = (C.c_float * 3)()
+        lib().p3dh_primary_ray(self.h, px, py, o, d)
+        return np.array(o, np.float32), np.array(d, np.float32)
+
+    def arrays(self):
+        """numpy views of the flattened scene (type, data12, material, materials12, lights6, bg)."""
+        d = self.desc()
+        n = d.n_prims
+        t = np.ctypeslib.as_array(d.prim_type, (n,)).copy() if n else np.zeros(0, np.uint32)
+        data = np.ctypeslib.as_array(d.prim_data, (n, 12)).copy() if n else np.zeros((0, 12), np.float32)
+        m = np.ctypeslib.as_array(d.prim_material, (n,)).copy() if n else np.zeros(0, np.uint32)
+        mats = np.ctypeslib.as_array(d.materials, (d.n_materials, 12)).copy()
+        li = np.ctypeslib.as_array(d.lights, (d.n_lights, 6)).copy() if d.n_lights else np.zeros((0, 6), np.float32)
+        return t, data, m, mats, li, np.array(d.background, np.float32)
+
+    def samples(self, seed, spp):
+        cam = self.camera()
+        out = np.zeros((self.res_y, self.res_x, spp * spp, 4), np.float32)
+        lib().p3dh_generate_samples(int(seed), self.res_x, self.res_y, int(spp), cam.aperture,
+                                    out.ctypes.data_as(C.c_void_p))
+        return out
+
+
+def make_desc(ptype, data12, material, materials12, lights6, bg):
+    """SceneDesc over caller-owned numpy arrays (returns (desc, keepalive))."""
+    ptype = np.ascontiguousarray(ptype, np.uint32)
+    data12 = np.ascontiguousarray(data12, np.float32).reshape(-1, 12)
+    material = np.ascontiguousarray(material, np.uint32)
+    materials12 = np.ascontiguousarray(materials12, np.float32).reshape(-1, 12)
+    lights6 = np.ascontiguousarray(lights6, np.float32).reshape(-1, 6)
+    d = SceneDesc()
+    d.n_prims = len(ptype)
+    d.prim_type = ptype.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.prim_data = data12.ctypes.data_as(C.POINTER(C.c_float))
+    d.prim_material = material.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.n_materials = len(materials12)
+    d.materials = materials12.ctypes.data_as(C.POINTER(C.c_float))
+    d.n_lights = len(lights6)
+    d.lights = lights6.ctypes.data_as(C.POINTER(C.c_float))
+    d.background = (C.c_float * 3)(*[float(v) for v in bg])
+    return d, (ptype, data12, material, materials12, lights6)
+
+
+class DeviceScene:
+    """p3d_scene on one GPU."""
+
+    def __init__(self, desc, device=0, leaf_max=0, keepalive=None):
+        self._keep = keepalive
+        self.h = C.c_void_p()
+        opts = BuildOpts(leaf_max, 0, 0)
+        _check(lib().p3d_scene_create(C.byref(desc), C.byref(opts), int(device), C.byref(self.h)),
+               "p3d_scene_create")
+        self.device = device
+
+    @classmethod
+    def from_host(cls, hs, device=0, leaf_max=0):
+        return cls(hs.desc(), device, leaf_max, keepalive=hs)
+
+    def close(self):
+        if self.h:
+            lib().p3d_scene_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stats(self):
+        s = SceneStats()
+        _check(lib().p3d_scene_get_stats(self.h, C.byref(s)), "p3d_scene_get_stats")
+        return s.as_dict()
+
+    def set_stream(self, stream_ptr):
+        _check(lib().p3d_set_stream(self.h, C.c_void_p(stream_ptr)), "p3d_set_stream")
+
+    def sync(self):
+        _check(lib().p3d_sync(self.h), "p3d_sync")
+
+    def timer_begin(self):
+        _check(lib().p3d_timer_begin(self.h), "p3d_timer_begin")
+
+    def timer_end(self):
+        ms = C.c_float(0)
+        _check(lib().p3d_timer_end(self.h, C.byref(ms)), "p3d_timer_end")
+        return ms.value
+
+    def counters(self):
+        c = Counters()
+        _check(lib().p3d_get_counters(self.h, C.byref(c)), "p3d_get_counters")
+        return c.as_dict()
+
+    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters):
+        p = RenderParams()
+        p.max_depth, p.accel, p.spp = int(max_depth), int(accel), int(spp)
+        p.samples = samples.ctypes.data_as(C.POINTER(C.c_float)) if samples is not None else None
+        p.row_block, p.rank, p.world = int(row_block), int(rank), int(world)
+        p.flags = FLAG_COUNTERS if counters else 0
+        return p
+
+    def render(self, cam, max_depth=4, accel=ACCEL_BVH, spp=0, samples=None, rank=0, world=1, row_block=16,
+               want_f32=True, want_hit=True, counters=False):
+        """Render into host numpy arrays (rows: res_y for world==1, local_rows otherwise)."""
+        rows = cam.res_y if world == 1 else local_rows(cam.res_y, row_block, world)
+        rgb8 = np.zeros((rows, cam.res_x, 3), np.uint8)
+        f32 = np.zeros((rows, cam.res_x, 3), np.float32) if want_f32 else None
+        hid = np.full((rows, cam.res_x), -2, np.int32) if want_hit else None
+        if samples is not None:
+            samples = np.ascontiguousarray(samples, np.float32)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters)
+        o = Outputs(rgb8.ctypes.data, f32.ctypes.data if want_f32 else None,
+                    hid.ctypes.data if want_hit else None, 0)
+        _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
+        out = {"rgb8": rgb8, "rgb32f": f32, "hit_id": hid}
+        if counters:
+            out["counters"] = self.counters()
+        return out
+
+    def render_device(self, cam, rgb8_ptr=0, rgb32f_ptr=0, hit_ptr=0, max_depth=4, accel=ACCEL_BVH, spp=0,
+                      samples=None, rank=0, world=1, row_block=16, counters=False):
+        """Enqueue one frame into caller-owned DEVICE buffers (raw pointers); asynchronous."""
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters)
+        o = Outputs(rgb8_ptr or None, rgb32f_ptr or None, hit_ptr or None, 1)
+        _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
+
+    def deinterleave(self, gathered_ptr, frame_ptr, res_x, res_y, row_block, world, bpp, rank_stride_bytes=0):
+        _check(lib().p3d_deinterleave(self.h, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), res_x, res_y,
+                                      row_block, world, bpp, int(rank_stride_bytes)), "p3d_deinterleave")
+
+
+def debug_intersect(ptype, prim12, origin, direction, device=0):
+    """Device intersectors on n (ray, primitive) pairs -> (hit[n] bool, t[n], normal[n,3])."""
+    ptype = np.ascontiguousarray(ptype, np.uint32)
+    prim12 = np.ascontiguousarray(prim12, np.float32).reshape(-1, 12)
+    origin = np.ascontiguousarray(origin, np.float32).reshape(-1, 3)
+    direction = np.ascontiguousarray(direction, np.float32).reshape(-1, 3)
+    n = len(ptype)
+    hit = np.zeros(n, np.int32)
+    t = np.zeros(n, np.float32)
+    nrm = np.zeros((n, 3), np.float32)
+    _check(lib().p3d_debug_intersect(int(device), n, ptype.ctypes.data, prim12.ctypes.data, origin.ctypes.data,
+                                     direction.ctypes.data, hit.ctypes.data, t.ctypes.data, nrm.ctypes.data),
+           "p3d_debug_intersect")
+    return hit.astype(bool), t, nrm
+
+
+def host_bvh(desc, leaf_max=0):
+    """Host-only BVH build (no GPU): dict(nodes [n,16] u32 view, refs, info)."""
+    h = lib().p3dh_bvh_build(C.byref(desc), int(leaf_max))
+    info = (C.c_uint32 * 5)()
+    lib().p3dh_bvh_info(h, info)
+    nodes = np.zeros((info[0], 16), np.uint32)
+    refs = np.zeros(info[1], np.uint32)
+    lib().p3dh_bvh_dump(h, nodes.ctypes.data, refs.ctypes.data)
+    lib().p3dh_bvh_free(h)
+    return {"nodes": nodes, "refs": refs, "n_leaves": int(info[2]), "max_depth": int(info[3]),
+            "n_prims": int(info[4])}

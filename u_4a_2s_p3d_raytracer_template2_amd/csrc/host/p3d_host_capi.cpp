@@ -1,0 +1,82 @@
+// p3d_host_capi.cpp -- flat C shim over the C++ host layer (p3d_scene.h) so that the Python
+// test / bench harness (ctypes) can drive the same loader, camera and sample generator the
+// C++ front end uses.  These p3dh_* functions are conveniences ABOVE the drop-in boundary;
+// the boundary itself is include/p3d_hip.h.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../bvh_builder.h"
+#include "../scene_flatten.h"
+#include "p3d_scene.h"
+
+using namespace p3d_host;
+
+struct p3dh_scene {
+    Scene scene;
+    Scene::Flat flat;
+};
+
+extern "C" {
+
+p3dh_scene* p3dh_scene_load(const char* path) {
+    p3dh_scene* h = new p3dh_scene();
+    if (!h->scene.load_p3f(path)) { delete h; return nullptr; }
+    h->scene.flatten(h->flat);
+    return h;
+}
+void p3dh_scene_free(p3dh_scene* h) { delete h; }
+
+// out[0..7] = n_prims, n_lights, n_materials, res_x, res_y, accel, spp, parse_ok
+void p3dh_scene_info(const p3dh_scene* h, int32_t* out) {
+    out[0] = (int32_t)h->flat.desc.n_prims; out[1] = (int32_t)h->flat.desc.n_lights;
+    out[2] = (int32_t)h->flat.desc.n_materials;
+    out[3] = h->scene.GetCamera()->GetResX(); out[4] = h->scene.GetCamera()->GetResY();
+    out[5] = (int32_t)h->scene.GetAccelStruct(); out[6] = (int32_t)h->scene.GetSamplesPerPixel();
+    out[7] = h->scene.parse_error().empty() ? 1 : 0;
+}
+void p3dh_scene_set_resolution(p3dh_scene* h, int32_t w, int32_t hh) { h->scene.GetCamera()->SetResolution(w, hh); }
+void p3dh_scene_set_eye(p3dh_scene* h, float x, float y, float z) { h->scene.GetCamera()->SetEye(Vector(x, y, z)); }
+// the flattened arrays stay owned by the handle
+void p3dh_scene_desc(const p3dh_scene* h, p3d_scene_desc* out) { *out = h->flat.desc; }
+void p3dh_scene_camera(const p3dh_scene* h, p3d_camera* out) { h->scene.GetCamera()->describe(out); }
+void p3dh_primary_ray(const p3dh_scene* h, float px, float py, float* o3, float* d3) {
+    Ray r = h->scene.GetCamera()->PrimaryRay(Vector(px, py, 0));
+    o3[0] = r.origin.x; o3[1] = r.origin.y; o3[2] = r.origin.z;
+    d3[0] = r.direction.x; d3[1] = r.direction.y; d3[2] = r.direction.z;
+}
+void p3dh_generate_samples(uint32_t seed, int32_t res_x, int32_t res_y, int32_t spp, float aperture, float* out) {
+    generate_samples(seed, res_x, res_y, spp, aperture, out);
+}
+
+// ---- host-only BVH build, for tests that run without a GPU
+struct p3dh_bvh {
+    std::vector<p3d::NodePair> nodes;
+    std::vector<uint32_t> refs;
+    std::vector<p3d::BuildPrim> prims;   // padded bounds, in the builder's final order
+    p3d::BvhStats stats;
+};
+p3dh_bvh* p3dh_bvh_build(const p3d_scene_desc* d, uint32_t leaf_max) {
+    p3d::FlatScene F;
+    if (!p3d::flatten_scene(*d, F).empty()) return nullptr;
+    p3dh_bvh* b = new p3dh_bvh();
+    b->prims = F.build_prims;
+    p3d::BvhOptions o;
+    if (leaf_max) o.leaf_max = leaf_max;
+    p3d::build_bvh(b->prims, o, b->nodes, b->refs, b->stats);
+    return b;
+}
+void p3dh_bvh_free(p3dh_bvh* b) { delete b; }
+// out[0..4] = n_nodes, n_leaf_refs, n_leaves, max_depth, n_prims
+void p3dh_bvh_info(const p3dh_bvh* b, uint32_t* out) {
+    out[0] = (uint32_t)b->nodes.size(); out[1] = (uint32_t)b->refs.size(); out[2] = b->stats.n_leaves;
+    out[3] = b->stats.max_depth; out[4] = (uint32_t)b->prims.size();
+}
+// nodes16: 16 dwords per node exactly as uploaded; refs: leaf reference list
+void p3dh_bvh_dump(const p3dh_bvh* b, uint32_t* nodes16, uint32_t* refs) {
+    memcpy(nodes16, b->nodes.data(), b->nodes.size() * sizeof(p3d::NodePair));
+    memcpy(refs, b->refs.data(), b->refs.size() * sizeof(uint32_t));
+}
+
+}  // extern "C"

@@ -1,0 +1,369 @@
+// p3d_capi.cpp -- implementation of the C-ABI declared in include/p3d_hip.h.
+// Host side only: flattens the caller's scene into the device records, builds the BVH
+// (bvh_builder.cpp), owns device memory and enqueues the kernels of p3d_kernels.hip.
+#include "p3d_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bvh_builder.h"
+#include "p3d_device_types.h"
+#include "scene_flatten.h"
+
+namespace p3d {
+size_t frame_kernel_lds_bytes(const LaunchParams& P);
+hipError_t launch_frame(const LaunchParams& P, bool count, hipStream_t stream);
+hipError_t prepare_frame_kernels(size_t max_lds);
+hipError_t launch_deinterleave(const void* gathered, void* frame, int res_x, int res_y, int row_block,
+                               int world, size_t rank_stride, int bpp, hipStream_t stream);
+hipError_t launch_debug_intersect(uint32_t n, const uint32_t* type, const float* prim12, const float* origin,
+                                  const float* dir, int32_t* hit, float* t, float* normal, hipStream_t stream);
+}  // namespace p3d
+
+using namespace p3d;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(P3D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t upload(const std::vector<T>& h) {
+        n = h.size();
+        size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        hipError_t e = hipMalloc((void**)&p, bytes);
+        if (e != hipSuccess) return e;
+        if (n) e = hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice);
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    size_t bytes() const { return std::max<size_t>(n, 1) * sizeof(T); }
+};
+
+struct RawBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct p3d_scene {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    DevBuf<NodePair> nodes;
+    DevBuf<uint32_t> leaf_refs;
+    DevBuf<SphereRec> spheres;
+    DevBuf<PrimMeta> sphere_meta;
+    DevBuf<TriRec> tris;
+    DevBuf<BoxRec> boxes;
+    DevBuf<PlaneRec> planes;
+    DevBuf<PrimMeta> plane_meta;
+    DevBuf<MaterialRec> materials;
+    DevBuf<LightRec> lights;
+    float bg[3] = {0, 0, 0};
+    uint32_t n_lights = 0, n_materials = 0;
+    p3d_scene_stats stats{};
+    RawBuf fb_rgb8, fb_rgb32f, fb_hit, samples;
+    DeviceCounters* d_counters = nullptr;
+    bool counters_valid = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timer_open = false;
+    size_t lds_prepared = 0;
+};
+
+extern "C" {
+
+int p3d_abi_version(void) { return P3D_ABI_VERSION; }
+const char* p3d_last_error(void) { return g_err.c_str(); }
+
+int p3d_device_count(int* count) {
+    if (!count) return fail(P3D_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(P3D_ERR_NO_DEVICE, hipGetErrorString(e)); }
+    *count = n;
+    return P3D_OK;
+}
+
+int p3d_local_rows(int32_t res_y, int32_t row_block, int32_t world) {
+    if (row_block <= 0) row_block = 16;
+    if (world <= 0) world = 1;
+    int nblocks = (res_y + row_block - 1) / row_block;
+    return ((nblocks + world - 1) / world) * row_block;
+}
+
+int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int device, p3d_scene** out) {
+    if (!d || !out) return fail(P3D_ERR_ARG, "desc/out is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(P3D_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(P3D_ERR_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    FlatScene F;
+    std::string why = flatten_scene(*d, F);
+    if (!why.empty()) return fail(why == "too many primitives" ? P3D_ERR_LIMIT : P3D_ERR_ARG, why);
+    BvhOptions bo;
+    if (opts) {
+        if (opts->leaf_max) bo.leaf_max = std::min<uint32_t>(opts->leaf_max, 8);
+        if (opts->sah_bins) bo.bins = opts->sah_bins;
+    }
+    std::vector<NodePair> nodes; std::vector<uint32_t> refs; BvhStats bs;
+    build_bvh(F.build_prims, bo, nodes, refs, bs);
+    std::vector<SphereRec>& spheres = F.spheres; std::vector<PrimMeta>& sphere_meta = F.sphere_meta;
+    std::vector<TriRec>& tris = F.tris; std::vector<BoxRec>& boxes = F.boxes;
+    std::vector<PlaneRec>& planes = F.planes; std::vector<PrimMeta>& plane_meta = F.plane_meta;
+    std::vector<MaterialRec>& mats = F.materials; std::vector<LightRec>& lights = F.lights;
+
+    p3d_scene* s = new p3d_scene();
+    s->device = device;
+    auto bail = [&](hipError_t e, const char* what) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+        p3d_scene_destroy(s);
+        return fail(P3D_ERR_HIP, msg);
+    };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    s->stream = s->own_stream;
+    if ((e = hipEventCreate(&s->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&s->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = s->nodes.upload(nodes)) != hipSuccess) return bail(e, "upload nodes");
+    if ((e = s->leaf_refs.upload(refs)) != hipSuccess) return bail(e, "upload leaf refs");
+    if ((e = s->spheres.upload(spheres)) != hipSuccess) return bail(e, "upload spheres");
+    if ((e = s->sphere_meta.upload(sphere_meta)) != hipSuccess) return bail(e, "upload sphere meta");
+    if ((e = s->tris.upload(tris)) != hipSuccess) return bail(e, "upload triangles");
+    if ((e = s->boxes.upload(boxes)) != hipSuccess) return bail(e, "upload boxes");
+    if ((e = s->planes.upload(planes)) != hipSuccess) return bail(e, "upload planes");
+    if ((e = s->plane_meta.upload(plane_meta)) != hipSuccess) return bail(e, "upload plane meta");
+    if ((e = s->materials.upload(mats)) != hipSuccess) return bail(e, "upload materials");
+    if ((e = s->lights.upload(lights)) != hipSuccess) return bail(e, "upload lights");
+    if ((e = hipMalloc((void**)&s->d_counters, sizeof(DeviceCounters))) != hipSuccess) return bail(e, "alloc counters");
+    if ((e = hipMemset(s->d_counters, 0, sizeof(DeviceCounters))) != hipSuccess) return bail(e, "clear counters");
+    memcpy(s->bg, d->background, sizeof s->bg);
+    s->n_lights = d->n_lights; s->n_materials = d->n_materials;
+    s->stats.n_nodes = bs.n_nodes; s->stats.n_leaves = bs.n_leaves; s->stats.max_depth = bs.max_depth;
+    s->stats.n_leaf_refs = bs.n_leaf_refs; s->stats.sah_cost = bs.sah_cost;
+    s->stats.n_spheres = (uint32_t)spheres.size(); s->stats.n_triangles = (uint32_t)tris.size();
+    s->stats.n_boxes = (uint32_t)boxes.size(); s->stats.n_planes = (uint32_t)planes.size();
+    s->stats.n_culled = 0;
+    s->stats.device_bytes = s->nodes.bytes() + s->leaf_refs.bytes() + s->spheres.bytes() + s->sphere_meta.bytes() +
+                            s->tris.bytes() + s->boxes.bytes() + s->planes.bytes() + s->plane_meta.bytes() +
+                            s->materials.bytes() + s->lights.bytes();
+    *out = s;
+    return P3D_OK;
+}
+
+int p3d_scene_destroy(p3d_scene* s) {
+    if (!s) return P3D_OK;
+    (void)hipSetDevice(s->device);
+    if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
+    s->nodes.release(); s->leaf_refs.release(); s->spheres.release(); s->sphere_meta.release();
+    s->tris.release(); s->boxes.release(); s->planes.release(); s->plane_meta.release();
+    s->materials.release(); s->lights.release();
+    s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release();
+    if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+    delete s;
+    return P3D_OK;
+}
+
+int p3d_scene_get_stats(const p3d_scene* s, p3d_scene_stats* out) {
+    if (!s || !out) return fail(P3D_ERR_ARG, "scene/out is NULL");
+    *out = s->stats;
+    return P3D_OK;
+}
+
+int p3d_set_stream(p3d_scene* s, void* hip_stream) {
+    if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
+    s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+    return P3D_OK;
+}
+
+int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm, const p3d_outputs* out) {
+    if (!s || !cam || !prm || !out) return fail(P3D_ERR_ARG, "NULL argument");
+    if (cam->res_x <= 0 || cam->res_y <= 0) return fail(P3D_ERR_ARG, "bad resolution");
+    if (prm->max_depth < 1 || prm->max_depth > 16) return fail(P3D_ERR_ARG, "max_depth must be in 1..16");
+    if (prm->accel < 0 || prm->accel > 2) return fail(P3D_ERR_ARG, "accel must be 0, 1 or 2");
+    if (prm->spp < 0 || prm->spp > 8) return fail(P3D_ERR_ARG, "spp must be in 0..8");
+    if (prm->spp > 0 && !prm->samples) return fail(P3D_ERR_ARG, "spp > 0 needs the host sample array");
+    int world = prm->world > 0 ? prm->world : 1;
+    int rank = prm->rank;
+    if (rank < 0 || rank >= world) return fail(P3D_ERR_ARG, "rank outside [0, world)");
+    int row_block = prm->row_block > 0 ? prm->row_block : 16;
+    if (row_block % 16) return fail(P3D_ERR_ARG, "row_block must be a multiple of 16");
+    HIP_TRY(hipSetDevice(s->device));
+
+    LaunchParams P;
+    memset(&P, 0, sizeof P);
+    P.nodes = s->nodes.p; P.leaf_refs = s->leaf_refs.p; P.spheres = s->spheres.p; P.sphere_meta = s->sphere_meta.p;
+    P.tris = s->tris.p; P.boxes = s->boxes.p; P.planes = s->planes.p; P.plane_meta = s->plane_meta.p;
+    P.materials = s->materials.p; P.lights = s->lights.p;
+    P.n_planes = s->stats.n_planes; P.n_lights = s->n_lights; P.n_materials = s->n_materials;
+    P.trav_stack_entries = std::max<uint32_t>(s->stats.max_depth + 1, 2);
+    memcpy(P.bg, s->bg, sizeof P.bg);
+    memcpy(P.eye, cam->eye, sizeof P.eye); memcpy(P.u, cam->u, sizeof P.u);
+    memcpy(P.v, cam->v, sizeof P.v); memcpy(P.n, cam->n, sizeof P.n);
+    P.w = cam->w; P.h = cam->h; P.plane_dist = cam->plane_dist; P.aperture = cam->aperture;
+    P.focal_ratio = cam->focal_ratio; P.res_x = cam->res_x; P.res_y = cam->res_y;
+    P.max_depth = prm->max_depth; P.accel = prm->accel; P.spp = prm->spp;
+    P.row_block = row_block; P.rank = rank; P.world = world;
+    P.local_rows = p3d_local_rows(cam->res_y, row_block, world);
+    P.tiles_x = (cam->res_x + 15) / 16; P.tiles_y = P.local_rows / 16;
+    P.n_tiles = P.tiles_x * P.tiles_y; P.tiles_per_xcd = (P.n_tiles + 7) / 8;
+    P.counters = s->d_counters;
+
+    size_t lds = frame_kernel_lds_bytes(P);
+    if (lds > kMaxLdsBytes) return fail(P3D_ERR_LIMIT, "BVH depth / max_depth need more LDS than a CU has");
+    if (lds > s->lds_prepared) {
+        HIP_TRY(prepare_frame_kernels(kMaxLdsBytes));
+        s->lds_prepared = kMaxLdsBytes;
+    }
+
+    const size_t npx = (size_t)P.local_rows * cam->res_x;
+    if (prm->spp > 0) {
+        size_t bytes = (size_t)cam->res_y * cam->res_x * prm->spp * prm->spp * 4 * sizeof(float);
+        HIP_TRY(s->samples.ensure(bytes));
+        HIP_TRY(hipMemcpyAsync(s->samples.p, prm->samples, bytes, hipMemcpyHostToDevice, s->stream));
+        P.samples = (const float*)s->samples.p;
+    }
+    if (out->memory == 1) {
+        P.rgb8 = out->rgb8; P.rgb32f = out->rgb32f; P.hit_id = out->hit_id;
+    } else {
+        if (out->rgb8) { HIP_TRY(s->fb_rgb8.ensure(npx * 3)); P.rgb8 = (uint8_t*)s->fb_rgb8.p; }
+        if (out->rgb32f) { HIP_TRY(s->fb_rgb32f.ensure(npx * 12)); P.rgb32f = (float*)s->fb_rgb32f.p; }
+        if (out->hit_id) { HIP_TRY(s->fb_hit.ensure(npx * 4)); P.hit_id = (int32_t*)s->fb_hit.p; }
+    }
+    bool count = (prm->flags & P3D_FLAG_COUNTERS) != 0;
+    if (count) {
+        HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), s->stream));
+        s->counters_valid = true;
+    }
+    HIP_TRY(launch_frame(P, count, s->stream));
+    if (out->memory != 1) {
+        // host planes hold res_y rows for a whole frame, p3d_local_rows() rows for a shard
+        const size_t cpx = (world == 1 ? (size_t)cam->res_y : (size_t)P.local_rows) * cam->res_x;
+        if (out->rgb8) HIP_TRY(hipMemcpyAsync(out->rgb8, P.rgb8, cpx * 3, hipMemcpyDeviceToHost, s->stream));
+        if (out->rgb32f) HIP_TRY(hipMemcpyAsync(out->rgb32f, P.rgb32f, cpx * 12, hipMemcpyDeviceToHost, s->stream));
+        if (out->hit_id) HIP_TRY(hipMemcpyAsync(out->hit_id, P.hit_id, cpx * 4, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    return P3D_OK;
+}
+
+int p3d_sync(p3d_scene* s) {
+    if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return P3D_OK;
+}
+
+int p3d_get_counters(p3d_scene* s, p3d_counters* out) {
+    if (!s || !out) return fail(P3D_ERR_ARG, "scene/out is NULL");
+    if (!s->counters_valid) return fail(P3D_ERR_STATE, "no render with P3D_FLAG_COUNTERS yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    DeviceCounters c;
+    HIP_TRY(hipMemcpy(&c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    out->closest_queries = c.closest_queries; out->shadow_queries = c.shadow_queries;
+    out->box_tests = c.box_tests; out->sphere_tests = c.sphere_tests; out->tri_tests = c.tri_tests;
+    out->aabox_tests = c.aabox_tests; out->plane_tests = c.plane_tests; out->pixels = c.pixels;
+    return P3D_OK;
+}
+
+int p3d_timer_begin(p3d_scene* s) {
+    if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    s->timer_open = true;
+    return P3D_OK;
+}
+
+int p3d_timer_end(p3d_scene* s, float* ms) {
+    if (!s || !ms) return fail(P3D_ERR_ARG, "scene/ms is NULL");
+    if (!s->timer_open) return fail(P3D_ERR_STATE, "p3d_timer_begin was not called");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    s->timer_open = false;
+    return P3D_OK;
+}
+
+int p3d_deinterleave(p3d_scene* s, const void* gathered, void* frame, int32_t res_x, int32_t res_y,
+                     int32_t row_block, int32_t world, int32_t bpp, uint64_t rank_stride_bytes) {
+    if (!s || !gathered || !frame) return fail(P3D_ERR_ARG, "NULL argument");
+    if (res_x <= 0 || res_y <= 0 || world <= 0) return fail(P3D_ERR_ARG, "bad sizes");
+    if (row_block <= 0) row_block = 16;
+    if (bpp != 3 && bpp != 4 && bpp != 12) return fail(P3D_ERR_ARG, "bytes_per_pixel must be 3, 4 or 12");
+    HIP_TRY(hipSetDevice(s->device));
+    size_t stride = rank_stride_bytes ? (size_t)rank_stride_bytes
+                                      : (size_t)p3d_local_rows(res_y, row_block, world) * res_x * bpp;
+    HIP_TRY(launch_deinterleave(gathered, frame, res_x, res_y, row_block, world, stride, bpp, s->stream));
+    return P3D_OK;
+}
+
+int p3d_debug_intersect(int device, uint32_t n, const uint32_t* type, const float* prim12, const float* origin,
+                        const float* dir, int32_t* hit, float* t, float* normal) {
+    if (!type || !prim12 || !origin || !dir || !hit || !t || !normal) return fail(P3D_ERR_ARG, "NULL argument");
+    if (n == 0) return P3D_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(P3D_ERR_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    uint32_t* d_type = nullptr; float *d_prim = nullptr, *d_o = nullptr, *d_d = nullptr, *d_t = nullptr, *d_n = nullptr;
+    int32_t* d_hit = nullptr;
+    int rc = P3D_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_type); (void)hipFree(d_prim); (void)hipFree(d_o); (void)hipFree(d_d);
+        (void)hipFree(d_t); (void)hipFree(d_n); (void)hipFree(d_hit);
+    };
+#define DBG_TRY(expr)                                                                                  \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(P3D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
+    DBG_TRY(hipMalloc((void**)&d_type, n * 4)); DBG_TRY(hipMalloc((void**)&d_prim, (size_t)n * 48));
+    DBG_TRY(hipMalloc((void**)&d_o, (size_t)n * 12)); DBG_TRY(hipMalloc((void**)&d_d, (size_t)n * 12));
+    DBG_TRY(hipMalloc((void**)&d_t, n * 4)); DBG_TRY(hipMalloc((void**)&d_n, (size_t)n * 12));
+    DBG_TRY(hipMalloc((void**)&d_hit, n * 4));
+    DBG_TRY(hipMemcpy(d_type, type, n * 4, hipMemcpyHostToDevice));
+    DBG_TRY(hipMemcpy(d_prim, prim12, (size_t)n * 48, hipMemcpyHostToDevice));
+    DBG_TRY(hipMemcpy(d_o, origin, (size_t)n * 12, hipMemcpyHostToDevice));
+    DBG_TRY(hipMemcpy(d_d, dir, (size_t)n * 12, hipMemcpyHostToDevice));
+    DBG_TRY(launch_debug_intersect(n, d_type, d_prim, d_o, d_d, d_hit, d_t, d_n, nullptr));
+    DBG_TRY(hipDeviceSynchronize());
+    DBG_TRY(hipMemcpy(hit, d_hit, n * 4, hipMemcpyDeviceToHost));
+    DBG_TRY(hipMemcpy(t, d_t, n * 4, hipMemcpyDeviceToHost));
+    DBG_TRY(hipMemcpy(normal, d_n, (size_t)n * 12, hipMemcpyDeviceToHost));
+#undef DBG_TRY
+    cleanup();
+    return rc;
+}
+
+}  // extern "C"

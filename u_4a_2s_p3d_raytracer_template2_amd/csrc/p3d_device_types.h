@@ -1,0 +1,72 @@
+// p3d_device_types.h -- POD records shared by the host uploader and the HIP kernels.
+// Layouts are sized for 16-byte vector loads (global_load_dwordx4); DESIGN.md §"Data layout".
+#ifndef P3D_DEVICE_TYPES_H
+#define P3D_DEVICE_TYPES_H
+
+#include <stdint.h>
+
+namespace p3d {
+
+// One BVH2 inner node = both children's boxes + both child references: 64 B, four
+// dwordx4 loads, two slab tests per visit (2 x 32 algorithmic bytes).
+// child >= 0: inner node index.  child < 0: leaf, ~child = (first_ref << 3) | (count - 1).
+// An absent child has NaN bounds (every slab comparison is false).
+struct NodePair {
+    float   lo0[3]; float hi0x;
+    float   hi0yz[2]; float lo1xy[2];
+    float   lo1z; float hi1[3];
+    int32_t child0, child1; uint32_t pad0, pad1;
+};
+static_assert(sizeof(NodePair) == 64, "NodePair must be 64 bytes");
+
+// leaf reference: kind in the top 2 bits, index into that kind's array below
+constexpr uint32_t kRefKindShift = 30;
+constexpr uint32_t kRefIndexMask = (1u << kRefKindShift) - 1u;
+
+struct SphereRec { float cx, cy, cz, r; };                                   // 16 B
+struct TriRec { float p0[3]; uint32_t scene_id; float e1[3]; uint32_t material;
+                float e2[3]; uint32_t pad; };                                // 48 B
+struct BoxRec { float mn[3]; uint32_t scene_id; float mx[3]; uint32_t material; };   // 32 B
+struct PlaneRec { float nx, ny, nz, d; };                                    // 16 B
+struct PrimMeta { uint32_t scene_id, material; };   // spheres and planes keep ids out of line
+
+struct MaterialRec { float diff[3]; float kd; float spec[3]; float ks;
+                     float shine, T, ior, refl; };                           // 48 B
+struct LightRec { float pos[3]; float pad0; float col[3]; float pad1; };     // 32 B
+
+struct DeviceCounters {
+    unsigned long long closest_queries, shadow_queries, box_tests, sphere_tests, tri_tests,
+        aabox_tests, plane_tests, pixels;
+};
+
+// Everything a render launch needs, passed by value (lands in SGPRs / kernarg segment).
+struct LaunchParams {
+    // scene
+    const NodePair*    nodes;
+    const uint32_t*    leaf_refs;
+    const SphereRec*   spheres;
+    const PrimMeta*    sphere_meta;
+    const TriRec*      tris;
+    const BoxRec*      boxes;
+    const PlaneRec*    planes;
+    const PrimMeta*    plane_meta;
+    const MaterialRec* materials;
+    const LightRec*    lights;
+    uint32_t n_planes, n_lights, n_materials, trav_stack_entries;
+    float bg[3];
+    // camera (RT/camera.h)
+    float eye[3], u[3], v[3], n[3];
+    float w, h, plane_dist, aperture, focal_ratio;
+    int32_t res_x, res_y;
+    // render
+    int32_t max_depth, accel, spp;
+    const float* samples;          // device copy of the host sample array or nullptr
+    int32_t row_block, rank, world, local_rows;
+    int32_t tiles_x, tiles_y, n_tiles, tiles_per_xcd;
+    // outputs (device)
+    uint8_t* rgb8; float* rgb32f; int32_t* hit_id;
+    DeviceCounters* counters;
+};
+
+}  // namespace p3d
+#endif
