@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -93,6 +94,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise P3DError("native extension %s is missing: run __graft_entry__.build() "
                        "(make -C u_4a_2s_p3d_raytracer_template2_amd/csrc)" % LIB_PATH)
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so (same
+    # SONAME as /opt/rocm's).  If torch is going to be used next to this library (bench.py,
+    # device-pointer outputs) it must be loaded FIRST so that both resolve to one runtime;
+    # two runtimes in one process leave the second without a visible GPU.
+    if "torch" not in sys.modules and os.environ.get("P3D_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     L.p3d_last_error.restype = C.c_char_p
     L.p3d_device_count.argtypes = [C.POINTER(C.c_int)]
