@@ -161,6 +161,11 @@ int p3d_sync(p3d_scene* scene);
 /* counters of the most recent render made with P3D_FLAG_COUNTERS (waits for it) */
 int p3d_get_counters(p3d_scene* scene, p3d_counters* out);
 
+/* Launch tuning that never changes results: xcd_chunk = consecutive 16x4-pixel tiles given
+ * to one XCD before moving to the next (1 = round robin, best load balance; larger = more
+ * L2 locality per XCD for big scenes). */
+int p3d_set_tuning(p3d_scene* scene, int32_t xcd_chunk);
+
 /* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the
  * scene's own stream. */
 int p3d_set_stream(p3d_scene* scene, void* hip_stream);

@@ -71,7 +71,7 @@ class SceneStats(C.Structure):
 # every symbol include/p3d_hip.h declares (tests check that the library exports them all)
 C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_scene_create",
                  "p3d_scene_destroy", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
-                 "p3d_get_counters", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end",
+                 "p3d_get_counters", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end",
                  "p3d_deinterleave", "p3d_debug_intersect"]
 
 
@@ -114,6 +114,7 @@ def lib():
     L.p3d_sync.argtypes = [C.c_void_p]
     L.p3d_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.p3d_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.p3d_set_tuning.argtypes = [C.c_void_p, C.c_int32]
     L.p3d_timer_begin.argtypes = [C.c_void_p]
     L.p3d_timer_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.p3d_deinterleave.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -275,6 +276,9 @@ class DeviceScene:
 
     def set_stream(self, stream_ptr):
         _check(lib().p3d_set_stream(self.h, C.c_void_p(stream_ptr)), "p3d_set_stream")
+
+    def set_tuning(self, xcd_chunk=1):
+        _check(lib().p3d_set_tuning(self.h, int(xcd_chunk)), "p3d_set_tuning")
 
     def sync(self):
         _check(lib().p3d_sync(self.h), "p3d_sync")

@@ -97,6 +97,7 @@ struct p3d_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timer_open = false;
     size_t lds_prepared = 0;
+    int xcd_chunk = 1;
 };
 
 extern "C" {
@@ -209,6 +210,13 @@ int p3d_set_stream(p3d_scene* s, void* hip_stream) {
     return P3D_OK;
 }
 
+int p3d_set_tuning(p3d_scene* s, int32_t xcd_chunk) {
+    if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
+    if (xcd_chunk < 1 || xcd_chunk > (1 << 20)) return fail(P3D_ERR_ARG, "xcd_chunk must be >= 1");
+    s->xcd_chunk = xcd_chunk;
+    return P3D_OK;
+}
+
 int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm, const p3d_outputs* out) {
     if (!s || !cam || !prm || !out) return fail(P3D_ERR_ARG, "NULL argument");
     if (cam->res_x <= 0 || cam->res_y <= 0) return fail(P3D_ERR_ARG, "bad resolution");
@@ -238,8 +246,14 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     P.max_depth = prm->max_depth; P.accel = prm->accel; P.spp = prm->spp;
     P.row_block = row_block; P.rank = rank; P.world = world;
     P.local_rows = p3d_local_rows(cam->res_y, row_block, world);
-    P.tiles_x = (cam->res_x + 15) / 16; P.tiles_y = P.local_rows / 16;
-    P.n_tiles = P.tiles_x * P.tiles_y; P.tiles_per_xcd = (P.n_tiles + 7) / 8;
+    const int tile_rows = 4 * kWavesPerGroup;
+    P.tiles_x = (cam->res_x + 15) / 16; P.tiles_y = P.local_rows / tile_rows;
+    P.n_tiles = P.tiles_x * P.tiles_y;
+    P.xcd_chunk = s->xcd_chunk > 0 ? s->xcd_chunk : 1;
+    {   // grid = whole chunks for all 8 XCDs (surplus blocks exit immediately)
+        int chunks = (P.n_tiles + P.xcd_chunk - 1) / P.xcd_chunk;
+        P.grid_blocks = ((chunks + 7) / 8) * 8 * P.xcd_chunk;
+    }
     P.counters = s->d_counters;
 
     size_t lds = frame_kernel_lds_bytes(P);

@@ -19,6 +19,10 @@ struct NodePair {
 };
 static_assert(sizeof(NodePair) == 64, "NodePair must be 64 bytes");
 
+// One wave (64 lanes = a 16x4 pixel tile) per workgroup: a wave's LDS and wave slot free up
+// the moment its own ray trees finish, instead of waiting for three neighbours.
+constexpr int kWavesPerGroup = 1;
+
 // leaf reference: kind in the top 2 bits, index into that kind's array below
 constexpr uint32_t kRefKindShift = 30;
 constexpr uint32_t kRefIndexMask = (1u << kRefKindShift) - 1u;
@@ -62,7 +66,7 @@ struct LaunchParams {
     int32_t max_depth, accel, spp;
     const float* samples;          // device copy of the host sample array or nullptr
     int32_t row_block, rank, world, local_rows;
-    int32_t tiles_x, tiles_y, n_tiles, tiles_per_xcd;
+    int32_t tiles_x, tiles_y, n_tiles, xcd_chunk, grid_blocks;
     // outputs (device)
     uint8_t* rgb8; float* rgb32f; int32_t* hit_id;
     DeviceCounters* counters;

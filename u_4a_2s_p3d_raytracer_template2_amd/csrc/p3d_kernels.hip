@@ -584,17 +584,22 @@ __device__ __forceinline__ Ray primary_ray_lens(const LaunchParams& P, float lx,
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void whitted_frame_kernel(const LaunchParams P) {
+__global__ __launch_bounds__(kWavesPerGroup * 64) void whitted_frame_kernel(const LaunchParams P) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // XCD-aware tile map: blocks b, b+8, b+16.. share an XCD -> give them adjacent tiles
+    // XCD-aware tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
+    // share one, each XCD has its own L2), so XCD k is given CHUNKS of xcd_chunk consecutive
+    // tiles: chunk c goes to XCD c % 8.  xcd_chunk = 1 is the identity map (best load balance:
+    // ray-tree depth is very uneven across the image), larger chunks trade balance for L2
+    // locality on scenes whose BVH does not fit one L2.
     const int bid = blockIdx.x;
-    const int tile = (bid & 7) * P.tiles_per_xcd + (bid >> 3);
+    const int j = bid >> 3;
+    const int tile = ((j / P.xcd_chunk) * 8 + (bid & 7)) * P.xcd_chunk + (j % P.xcd_chunk);
     if (tile >= P.n_tiles) return;
     const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
     const int lx = lane & 15, ly = (lane >> 4) + wave * 4;
     const int x = tx * 16 + lx;
-    const int row = ty * 16 + ly;                        // row in the compact local buffer
+    const int row = ty * (kWavesPerGroup * 4) + ly;      // row in the compact local buffer
     const int blk = row / P.row_block;
     const int y = (blk * P.world + P.rank) * P.row_block + (row - blk * P.row_block);
     if (x >= P.res_x || y >= P.res_y) return;            // no barriers below: early exit is safe
@@ -709,12 +714,12 @@ __global__ void debug_intersect_kernel(uint32_t n, const uint32_t* type, const f
 size_t frame_kernel_lds_bytes(const LaunchParams& P) {
     int frames = P.max_depth > 1 ? (P.max_depth - 1) : 1;
     size_t wave_dwords = (size_t)P.trav_stack_entries * 128 + (size_t)frames * 12 * 64;
-    return wave_dwords * 4 * 4;   // 4 waves per workgroup
+    return wave_dwords * 4 * kWavesPerGroup;
 }
 
 hipError_t launch_frame(const LaunchParams& P, bool count, hipStream_t stream) {
     size_t lds = frame_kernel_lds_bytes(P);
-    dim3 grid((unsigned)(P.tiles_per_xcd * 8)), block(256);
+    dim3 grid((unsigned)P.grid_blocks), block(kWavesPerGroup * 64);
     if (count) {
         hipLaunchKernelGGL(whitted_frame_kernel<true>, grid, block, lds, stream, P);
     } else {
