@@ -100,7 +100,11 @@ typedef struct p3d_render_params {
     uint32_t flags;          /* P3D_FLAG_*                                              */
 } p3d_render_params;
 
-#define P3D_FLAG_COUNTERS 1u  /* accumulate p3d_counters on the device (slower kernel)   */
+#define P3D_FLAG_COUNTERS 1u     /* accumulate p3d_counters on the device (slower kernels)  */
+#define P3D_FLAG_TREE_KERNEL 2u  /* one launch, per-lane post-order frame stack in LDS, instead
+                                    of the default level-by-level wavefront schedule; results are
+                                    bit-identical (also the automatic fallback when the wavefront
+                                    queues for max_depth would not fit the workspace budget)    */
 
 /* Work counters in the unit of SURVEY §8d (one ray = one closest-hit or shadow query). */
 typedef struct p3d_counters {
@@ -161,10 +165,11 @@ int p3d_sync(p3d_scene* scene);
 /* counters of the most recent render made with P3D_FLAG_COUNTERS (waits for it) */
 int p3d_get_counters(p3d_scene* scene, p3d_counters* out);
 
-/* Launch tuning that never changes results: xcd_chunk = consecutive 16x4-pixel tiles given
- * to one XCD before moving to the next (1 = round robin, best load balance; larger = more
- * L2 locality per XCD for big scenes). */
-int p3d_set_tuning(p3d_scene* scene, int32_t xcd_chunk);
+/* Launch tuning that never changes results (0 keeps the current value): xcd_chunk =
+ * consecutive 16x4-pixel tiles given to one XCD before moving to the next (1 = round robin,
+ * best load balance; larger = more L2 locality per XCD for big scenes); workspace_mib = HBM
+ * budget for the wavefront ray queues (default 8192; frames that need more run in bands). */
+int p3d_set_tuning(p3d_scene* scene, int32_t xcd_chunk, int32_t workspace_mib);
 
 /* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the
  * scene's own stream. */

@@ -101,10 +101,11 @@ def test_device_intersectors_match_oracle_live_including_planes():
     assert np.array_equal(t[hit].view(np.uint32), exp_t[hit].view(np.uint32))
 
 
+@pytest.mark.parametrize("schedule", ["wavefront", "tree"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_frame_matches_golden_fixture(frames, name):
+def test_frame_matches_golden_fixture(frames, name, schedule):
     m = CASES[name]
-    out = gpu_render(m, counters=True)
+    out = gpu_render(m, counters=True, tree=(schedule == "tree"))
     compare(out, frames[name + "/rgb8"], frames[name + "/rgb32f"], frames[name + "/hit_id"], name)
     c = out["counters"]
     assert c["closest_queries"] == m["counters"]["closest_queries"], name
@@ -117,6 +118,28 @@ def test_result_is_independent_of_the_bvh_shape(frames, leaf_max):
     for name in ("c2_mount_low_256x144_d4_bvh", "balls_box_128_d4_none", "c3_dragon_96_d4_bvh"):
         out = gpu_render(CASES[name], leaf_max=leaf_max)
         compare(out, frames[name + "/rgb8"], frames[name + "/rgb32f"], frames[name + "/hit_id"], name)
+
+
+def test_wavefront_and_tree_schedules_are_bit_identical():
+    for name in ("c2_mount_low_256x144_d4_bvh", "c4_mount_low_96_d6_spp2", "balls_box_128_d4_bvh", "dof_64_d4_spp4"):
+        a = gpu_render(CASES[name], counters=True)
+        b = gpu_render(CASES[name], counters=True, tree=True)
+        assert np.array_equal(a["rgb8"], b["rgb8"]) and np.array_equal(a["hit_id"], b["hit_id"]), name
+        assert np.array_equal(a["rgb32f"].view(np.uint32), b["rgb32f"].view(np.uint32)), name
+        assert a["counters"] == b["counters"], name
+
+
+def test_wavefront_bands_do_not_change_the_image():
+    """A tiny workspace budget forces the wavefront schedule to run the frame in bands."""
+    m = CASES["c2_mount_low_256x144_d4_bvh"]
+    hs = P.HostScene(scene_path(m["scene"])); hs.set_resolution(*m["res"])
+    ds = P.DeviceScene.from_host(hs)
+    full = ds.render(hs.camera(), accel=2)
+    ds.set_tuning(workspace_mib=1)          # 1 MiB: a few tile rows per band
+    banded = ds.render(hs.camera(), accel=2)
+    assert np.array_equal(full["rgb8"], banded["rgb8"]) and np.array_equal(full["hit_id"], banded["hit_id"])
+    assert np.array_equal(full["rgb32f"].view(np.uint32), banded["rgb32f"].view(np.uint32))
+    ds.close()
 
 
 def test_config2_full_size_against_live_oracle():

@@ -21,6 +21,7 @@ ap.add_argument("--depth", type=int, default=4)
 ap.add_argument("--accel", type=int, default=2)
 ap.add_argument("--leaf", type=int, default=0)
 ap.add_argument("--n", type=int, default=50)
+ap.add_argument("--tree", action="store_true")
 a = ap.parse_args()
 
 import torch  # noqa: E402
@@ -34,16 +35,18 @@ ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=a.depth, accel=a.accel,
 c = ds.counters()
 print("counters", c)
 ref = None
-for ch in [int(v) for v in a.chunks.split(",")]:
-    ds.set_tuning(xcd_chunk=ch)
-    for _ in range(5):
-        ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=a.depth, accel=a.accel)
-    ds.timer_begin()
-    for _ in range(a.n):
-        ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=a.depth, accel=a.accel)
-    ms = ds.timer_end() / a.n
-    img = buf.cpu().numpy()
-    if ref is None:
-        ref = img
-    print("xcd_chunk %6d: %.4f ms/frame  %.1f Mrays/s  alg %.0f GB/s  same_image=%s" % (
-        ch, ms, c["rays"] / ms / 1e3, (c["algorithmic_bytes"] + 3 * c["pixels"]) / ms / 1e6, np.array_equal(img, ref)))
+for tree in ([False, True] if not a.tree else [True]):
+    for ch in [int(v) for v in a.chunks.split(",")]:
+        ds.set_tuning(xcd_chunk=ch)
+        for _ in range(5):
+            ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=a.depth, accel=a.accel, tree=tree)
+        ds.timer_begin()
+        for _ in range(a.n):
+            ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=a.depth, accel=a.accel, tree=tree)
+        ms = ds.timer_end() / a.n
+        img = buf.cpu().numpy()
+        if ref is None:
+            ref = img
+        print("%s xcd_chunk %6d: %.4f ms/frame  %.1f Mrays/s  alg %.0f GB/s  same_image=%s" % (
+            "tree     " if tree else "wavefront", ch, ms, c["rays"] / ms / 1e3,
+            (c["algorithmic_bytes"] + 3 * c["pixels"]) / ms / 1e6, np.array_equal(img, ref)))

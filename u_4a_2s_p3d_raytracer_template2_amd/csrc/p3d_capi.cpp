@@ -17,9 +17,13 @@
 #include "scene_flatten.h"
 
 namespace p3d {
-size_t frame_kernel_lds_bytes(const LaunchParams& P);
-hipError_t launch_frame(const LaunchParams& P, bool count, hipStream_t stream);
-hipError_t prepare_frame_kernels(size_t max_lds);
+size_t tree_kernel_lds_bytes(const LaunchParams& P);
+size_t wavefront_lds_bytes(const LaunchParams& P);
+hipError_t launch_tree(const LaunchParams& P, bool count, hipStream_t stream);
+hipError_t launch_wf_primary(const LaunchParams& P, bool count, hipStream_t stream);
+hipError_t launch_wf_secondary(const LaunchParams& P, bool count, unsigned waves, hipStream_t stream);
+hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream);
+hipError_t prepare_kernels(size_t max_lds);
 hipError_t launch_deinterleave(const void* gathered, void* frame, int res_x, int res_y, int row_block,
                                int world, size_t rank_stride, int bpp, hipStream_t stream);
 hipError_t launch_debug_intersect(uint32_t n, const uint32_t* type, const float* prim12, const float* origin,
@@ -42,6 +46,8 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU
+constexpr int kMaxDepth = 16;
+constexpr unsigned kPersistentWaves = 256 * 16;   // secondary-level launches: waves that stride over the queue
 
 template <typename T>
 struct DevBuf {
@@ -92,6 +98,9 @@ struct p3d_scene {
     uint32_t n_lights = 0, n_materials = 0;
     p3d_scene_stats stats{};
     RawBuf fb_rgb8, fb_rgb32f, fb_hit, samples;
+    // wavefront workspace: ray queues (levels 2..D), parked nodes (levels 1..D-1), counters
+    RawBuf wf_rays[kMaxDepth + 2], wf_nodes[kMaxDepth + 2], wf_counts, wf_accum;
+    size_t workspace_budget = (size_t)8 << 30;
     DeviceCounters* d_counters = nullptr;
     bool counters_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -190,6 +199,9 @@ int p3d_scene_destroy(p3d_scene* s) {
     s->tris.release(); s->boxes.release(); s->planes.release(); s->plane_meta.release();
     s->materials.release(); s->lights.release();
     s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release();
+    for (auto& b : s->wf_rays) b.release();
+    for (auto& b : s->wf_nodes) b.release();
+    s->wf_counts.release(); s->wf_accum.release();
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -210,12 +222,57 @@ int p3d_set_stream(p3d_scene* s, void* hip_stream) {
     return P3D_OK;
 }
 
-int p3d_set_tuning(p3d_scene* s, int32_t xcd_chunk) {
+int p3d_set_tuning(p3d_scene* s, int32_t xcd_chunk, int32_t workspace_mib) {
     if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
-    if (xcd_chunk < 1 || xcd_chunk > (1 << 20)) return fail(P3D_ERR_ARG, "xcd_chunk must be >= 1");
-    s->xcd_chunk = xcd_chunk;
+    if (xcd_chunk < 0 || xcd_chunk > (1 << 20)) return fail(P3D_ERR_ARG, "xcd_chunk must be >= 0");
+    if (workspace_mib < 0) return fail(P3D_ERR_ARG, "workspace_mib must be >= 0");
+    if (xcd_chunk) s->xcd_chunk = xcd_chunk;
+    if (workspace_mib) s->workspace_budget = (size_t)workspace_mib << 20;
     return P3D_OK;
 }
+
+namespace {
+
+// worst-case workspace bytes per pixel for a depth-D tree: level l holds at most 2^(l-1) rays
+size_t wavefront_bytes_per_pixel(int D) {
+    size_t b = 0;
+    for (int l = 2; l <= D; l++) b += ((size_t)1 << (l - 1)) * sizeof(RayRec);
+    for (int l = 1; l <= D - 1; l++) b += ((size_t)1 << (l - 1)) * sizeof(NodeRec);
+    return b;
+}
+
+// One sample pass over one band of tile rows, level by level (see p3d_kernels.hip).
+int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, size_t band_px) {
+    const int D = P.max_depth;
+    uint32_t* counts = (uint32_t*)s->wf_counts.p;      // [0..31] ray queue sizes, [32..63] node counts
+    HIP_TRY(hipMemsetAsync(counts, 0, 64 * sizeof(uint32_t), s->stream));
+    auto rays = [&](int l) { return (l >= 2 && l <= D) ? (RayRec*)s->wf_rays[l].p : nullptr; };
+    auto nodes = [&](int l) { return (l >= 1 && l <= D - 1) ? (NodeRec*)s->wf_nodes[l].p : nullptr; };
+    P.wf_level = 1;
+    P.wf_rays_in = nullptr; P.wf_count_in = nullptr;
+    P.wf_rays_out = rays(2); P.wf_count_out = counts + 2;
+    P.wf_nodes_parent = nullptr; P.wf_nodes_self = nodes(1); P.wf_ncount_self = counts + 32 + 1;
+    HIP_TRY(launch_wf_primary(P, count, s->stream));
+    for (int l = 2; l <= D; l++) {
+        P.wf_level = l;
+        P.wf_rays_in = rays(l); P.wf_count_in = counts + l;
+        P.wf_rays_out = rays(l + 1); P.wf_count_out = counts + l + 1;
+        P.wf_nodes_parent = nodes(l - 1); P.wf_nodes_self = nodes(l); P.wf_ncount_self = counts + 32 + l;
+        size_t cap = band_px << (l - 1);
+        unsigned waves = (unsigned)std::min<size_t>((cap + 63) / 64, kPersistentWaves);
+        HIP_TRY(launch_wf_secondary(P, count, waves, s->stream));
+    }
+    for (int l = D - 1; l >= 1; l--) {
+        P.wf_level = l;
+        P.wf_nodes_self = nodes(l); P.wf_ncount_self = counts + 32 + l; P.wf_nodes_parent = nodes(l - 1);
+        size_t cap = band_px << (l - 1);
+        unsigned blocks = (unsigned)std::min<size_t>((cap + 255) / 256, 2048);
+        HIP_TRY(launch_wf_resolve(P, blocks, s->stream));
+    }
+    return P3D_OK;
+}
+
+}  // namespace
 
 int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm, const p3d_outputs* out) {
     if (!s || !cam || !prm || !out) return fail(P3D_ERR_ARG, "NULL argument");
@@ -256,10 +313,18 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     }
     P.counters = s->d_counters;
 
-    size_t lds = frame_kernel_lds_bytes(P);
+    const bool tree_requested = (prm->flags & P3D_FLAG_TREE_KERNEL) != 0;
+    // wavefront bands: worst-case queues for a band of tile rows must fit the workspace budget
+    const size_t tile_row_px = (size_t)P.tiles_x * 64 * kWavesPerGroup;
+    const size_t wf_bpp = wavefront_bytes_per_pixel(prm->max_depth) + (prm->spp > 0 ? 12 : 0);
+    size_t band_tile_rows = wf_bpp ? s->workspace_budget / (wf_bpp * tile_row_px) : (size_t)P.tiles_y;
+    if (wf_bpp == 0) band_tile_rows = (size_t)P.tiles_y;
+    band_tile_rows = std::min<size_t>(band_tile_rows, (size_t)P.tiles_y);
+    const bool use_tree = tree_requested || band_tile_rows == 0;
+    size_t lds = use_tree ? tree_kernel_lds_bytes(P) : wavefront_lds_bytes(P);
     if (lds > kMaxLdsBytes) return fail(P3D_ERR_LIMIT, "BVH depth / max_depth need more LDS than a CU has");
-    if (lds > s->lds_prepared) {
-        HIP_TRY(prepare_frame_kernels(kMaxLdsBytes));
+    if (lds > 64 * 1024 && !s->lds_prepared) {
+        HIP_TRY(prepare_kernels(kMaxLdsBytes));
         s->lds_prepared = kMaxLdsBytes;
     }
 
@@ -282,7 +347,32 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), s->stream));
         s->counters_valid = true;
     }
-    HIP_TRY(launch_frame(P, count, s->stream));
+    P.wf_nsamples = prm->spp > 0 ? prm->spp * prm->spp : 1;
+    if (use_tree) {
+        P.wf_tile_row0 = 0; P.wf_tile_rows = P.tiles_y;
+        HIP_TRY(launch_tree(P, count, s->stream));
+    } else {
+        const int D = prm->max_depth;
+        const size_t band_px = band_tile_rows * tile_row_px;
+        for (int l = 2; l <= D; l++) HIP_TRY(s->wf_rays[l].ensure((band_px << (l - 1)) * sizeof(RayRec)));
+        for (int l = 1; l <= D - 1; l++) HIP_TRY(s->wf_nodes[l].ensure((band_px << (l - 1)) * sizeof(NodeRec)));
+        HIP_TRY(s->wf_counts.ensure(64 * sizeof(uint32_t)));
+        if (prm->spp > 0) { HIP_TRY(s->wf_accum.ensure(npx * 12)); P.wf_accum = (float*)s->wf_accum.p; }
+        // samples outermost: a pixel's clamped sample colours are summed in sample order
+        for (int smp = 0; smp < P.wf_nsamples; smp++) {
+            P.wf_sample = smp;
+            for (size_t r0 = 0; r0 < (size_t)P.tiles_y; r0 += band_tile_rows) {
+                LaunchParams B = P;
+                B.wf_tile_row0 = (int32_t)r0;
+                B.wf_tile_rows = (int32_t)std::min<size_t>(band_tile_rows, (size_t)P.tiles_y - r0);
+                B.n_tiles = B.tiles_x * B.wf_tile_rows;
+                int chunks = (B.n_tiles + B.xcd_chunk - 1) / B.xcd_chunk;
+                B.grid_blocks = ((chunks + 7) / 8) * 8 * B.xcd_chunk;
+                int rc = run_wavefront_pass(s, B, count, band_px);
+                if (rc) return rc;
+            }
+        }
+    }
     if (out->memory != 1) {
         // host planes hold res_y rows for a whole frame, p3d_local_rows() rows for a shard
         const size_t cpx = (world == 1 ? (size_t)cam->res_y : (size_t)P.local_rows) * cam->res_x;

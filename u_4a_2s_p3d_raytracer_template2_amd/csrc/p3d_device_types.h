@@ -38,6 +38,18 @@ struct MaterialRec { float diff[3]; float kd; float spec[3]; float ks;
                      float shine, T, ior, refl; };                           // 48 B
 struct LightRec { float pos[3]; float pad0; float col[3]; float pad1; };     // 32 B
 
+// ---- wavefront workspace records (one kernel per tree level, DESIGN.md §"Kernels")
+// A queued ray of level d >= 2.  link = index of its parent's NodeRec at level d-1, bit 31 set
+// for the refraction child (clear for the reflection child).
+struct RayRec { float o[3]; float ior; float d[3]; uint32_t link; };         // 32 B
+// A tree node that is waiting for children.  Children (or the resolve pass of the level below)
+// overwrite refl_ret / refr_ret; both start as zero, which is what the reference adds for a
+// child it never traced.  link = parent NodeRec like RayRec::link, or the compact pixel index
+// for level-1 nodes.
+struct NodeRec { float color[3]; float KR; float refl_ret[3]; uint32_t mat;
+                 float refr_ret[3]; uint32_t link; };                        // 48 B
+constexpr uint32_t kLinkRefr = 0x80000000u;
+
 struct DeviceCounters {
     unsigned long long closest_queries, shadow_queries, box_tests, sphere_tests, tri_tests,
         aabox_tests, plane_tests, pixels;
@@ -70,6 +82,15 @@ struct LaunchParams {
     // outputs (device)
     uint8_t* rgb8; float* rgb32f; int32_t* hit_id;
     DeviceCounters* counters;
+    // wavefront pass state (set per launch by the host)
+    int32_t wf_level;              // tree level this launch traces / resolves (1 = primary rays)
+    int32_t wf_sample, wf_nsamples;
+    int32_t wf_tile_row0, wf_tile_rows;      // band of 16x4-tile rows handled by this pass
+    const RayRec* wf_rays_in;  const uint32_t* wf_count_in;      // level wf_level queue
+    RayRec* wf_rays_out;       uint32_t* wf_count_out;           // level wf_level + 1 queue
+    NodeRec* wf_nodes_parent;                                     // level wf_level - 1 nodes
+    NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
+    float* wf_accum;                                              // [local px][3] running sample sum
 };
 
 }  // namespace p3d

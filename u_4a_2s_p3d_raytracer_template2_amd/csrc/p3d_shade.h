@@ -1,0 +1,194 @@
+// p3d_shade.h -- one node of the reference's shading recursion (rayTracing(),
+// RT/main.cpp:530-721, and processLight(), RT/main.cpp:471-526) as a non-recursive function:
+// shade_hit() returns the node's direct colour, its mixing weight KR and the child rays it
+// spawns; the caller (wavefront level kernels or the single-launch tree kernel) decides how the
+// children are scheduled and combines them with combine_node() in the reference's order.
+#ifndef P3D_SHADE_H
+#define P3D_SHADE_H
+
+#include "p3d_traverse.h"
+
+namespace p3d {
+
+// getNormal(point).normalize() of the hit primitive (RT/main.cpp:587-589)
+__device__ __forceinline__ V3 prim_normal(const LaunchParams& P, uint32_t ref, const Ray& r, V3 point) {
+    uint32_t kind = ref >> kRefKindShift, idx = ref & kRefIndexMask;
+    if (kind == 0u) {                                                   // RT/scene.cpp:174-178
+        float4 s = *reinterpret_cast<const float4*>(P.spheres + idx);
+        V3 n = normalized(sub(point, mk(s.x, s.y, s.z)));
+        return normalized(n);
+    } else if (kind == 1u) {                                            // RT/scene.cpp:10-25,46-49
+        const float4* tp = reinterpret_cast<const float4*>(P.tris + idx);
+        float4 b = tp[1], c = tp[2];
+        V3 V = mk(b.x, b.y, b.z), W = mk(c.x, c.y, c.z);
+        V3 n = mk((V.y * W.z) - (V.z * W.y), (V.z * W.x) - (V.x * W.z), (V.x * W.y) - (V.y * W.x));
+        n = normalized(n);
+        return normalized(n);
+    } else if (kind == 2u) {
+        const float4* bp = reinterpret_cast<const float4*>(P.boxes + idx);
+        float4 a = bp[0], b = bp[1];
+        float t; V3 nn = mk(0.0f, 0.0f, 0.0f);
+        hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
+        return normalized(nn);
+    } else {                                                            // RT/scene.cpp:143-146
+        PlaneRec pl = P.planes[idx];
+        return normalized(mk(pl.nx, pl.ny, pl.nz));
+    }
+}
+
+struct Mtl { V3 diff; float kd; V3 spec; float ks; float shine, T, ior, refl; };
+__device__ __forceinline__ Mtl load_material(const LaunchParams& P, uint32_t m) {
+    const float4* mp = reinterpret_cast<const float4*>(P.materials + m);
+    float4 a = mp[0], b = mp[1], c = mp[2];
+    Mtl r; r.diff = mk(a.x, a.y, a.z); r.kd = a.w; r.spec = mk(b.x, b.y, b.z); r.ks = b.w;
+    r.shine = c.x; r.T = c.y; r.ior = c.z; r.refl = c.w;
+    return r;
+}
+
+
+// processLight(), RT/main.cpp:471-526
+template <bool COUNT>
+__device__ __forceinline__ void process_light(const LaunchParams& P, V3 L, V3 lcol, V3& color, const Mtl& M,
+                                              const Ray& ray, V3 precise, V3 normal, TravStack st, Ctr& ctr) {
+    bool insideShadow = false;
+    if (dot(L, normal) > 0.0f) {
+        Ray sr; sr.o = precise; sr.d = L;
+        if (P.accel == 0) {
+            insideShadow = any_hit<COUNT>(P, sr, false, 0.0f, st, ctr);
+        } else {
+            float length = vlen(sr.d);              // BVH::Traverse(Ray&), RT/bvh.cpp:351-352
+            sr.d = normalized(sr.d);
+            insideShadow = any_hit<COUNT>(P, sr, true, length, st, ctr);
+        }
+    }
+    if (!insideShadow) {
+        L = normalized(L);
+        V3 H = normalized(add(L, mul(ray.d, -1.0f)));
+        float VdotN = dot(H, normal);
+        float d1 = dot(normal, L);
+        float max1 = (0.0f < d1) ? d1 : 0.0f;        // std::max(0.0f, x)
+        float max2 = (0.0f < VdotN) ? VdotN : 0.0f;
+        V3 diff = mul(cmul(lcol, M.diff), max1);
+        V3 spec = mul(cmul(lcol, M.spec), powf(max2, M.shine));
+        color = add(color, add(mul(diff, M.kd), mul(mul(spec, M.ks), 0.4f)));
+    }
+}
+
+
+// What one rayTracing() invocation produces before its recursive calls return.
+struct NodeOut {
+    bool terminal;          // true: `ret` is this invocation's return value already
+    V3 ret;                 // valid when terminal
+    V3 color;               // direct lighting sum (the reference's `color` before recursion)
+    float KR;
+    uint32_t mat;
+    bool has_refl, has_refr;
+    Ray refl, refr;         // child rays; the reflection child keeps ior_1, the refraction child gets newIor
+    float newIor;
+};
+
+// colour returned by a node once its children returned refl_ret / refr_ret (zero when the
+// child was never traced): "color += reflection_color * KR * specColor + refraction_color *
+// (1 - KR)", RT/main.cpp:719, same association.
+__device__ __forceinline__ V3 combine_node(V3 color, float KR, V3 spec, V3 refl_ret, V3 refr_ret) {
+    return add(color, add(cmul(mul(refl_ret, KR), spec), mul(refr_ret, 1.0f - KR)));
+}
+
+// rayTracing(ray, depth, ior_1) up to (not including) its recursive calls.
+template <bool COUNT>
+__device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const Ray& ray, const Hit& h, int depth,
+                                             float ior_1, TravStack st, Ctr& ctr) {
+    NodeOut o;
+    o.terminal = true; o.KR = 0.0f; o.mat = h.mat; o.has_refl = false; o.has_refr = false; o.newIor = 1.0f;
+    o.color = mk(0.0f, 0.0f, 0.0f);
+    o.refl.o = o.color; o.refl.d = o.color; o.refr.o = o.color; o.refr.d = o.color;
+    if (h.ref == 0xFFFFFFFFu) {
+        o.ret = mk(P.bg[0], P.bg[1], P.bg[2]);
+        return o;
+    }
+    Mtl M = load_material(P, h.mat);
+    V3 hit_point = add(ray.o, mul(ray.d, h.t));
+    V3 normal = prim_normal(P, h.ref, ray, hit_point);
+    V3 precise = add(hit_point, mul(normal, P3D_EPS));
+    normal = prim_normal(P, h.ref, ray, precise);
+    V3 Vv = mul(ray.d, -1.0f);
+    V3 color = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t i = 0; i < P.n_lights; i++) {
+        const float4* lp = reinterpret_cast<const float4*>(P.lights + i);
+        float4 lpos = lp[0], lcol = lp[1];
+        V3 L = sub(mk(lpos.x, lpos.y, lpos.z), hit_point);
+        process_light<COUNT>(P, L, mk(lcol.x, lcol.y, lcol.z), color, M, ray, precise, normal, st, ctr);
+    }
+    o.color = color;
+    if (depth >= P.max_depth) {                                          // RT/main.cpp:632-634
+        o.ret = clampc(color);
+        return o;
+    }
+    bool inside = false;
+    if (dot(ray.d, normal) > 0.0f) { normal = mul(normal, -1.0f); inside = true; }
+    if (M.refl > 0.0f) {                                                 // RT/main.cpp:646-667
+        V3 rdir = sub(ray.d, mul(mul(normal, dot(ray.d, normal)), 2.0f));
+        o.refl.o = precise;
+        o.refl.d = normalized(rdir);
+        o.has_refl = true;
+    }
+    float KR;
+    if (M.T != 0.0f) {                                                   // RT/main.cpp:671-713
+        float R0 = 1.0f, R1 = 1.0f;
+        V3 viewnormal = mul(normal, dot(normal, Vv));
+        V3 viewtangent = sub(viewnormal, Vv);
+        float nn = inside ? ior_1 : fdiv(ior_1, M.ior);
+        float cos_i = vlen(viewnormal);
+        float sin_t = nn * vlen(viewtangent);
+        float insqrt = (float)(1.0 - (double)sin_t * (double)sin_t);     // pow(float, 2) is double
+        if (insqrt >= 0.0f) {
+            float cos_t = fsqrt(insqrt);
+            V3 rfr = add(mul(normalized(viewtangent), sin_t), normalized(mul(normal, cos_t)));
+            o.refr.o = add(hit_point, mul(rfr, 0.001f));
+            o.refr.d = rfr;
+            o.newIor = inside ? 1.0f : M.ior;
+            o.has_refr = true;
+            float den = ior_1 * cos_i + o.newIor * cos_t;
+            float q0 = fabsf(fdiv(ior_1 * cos_i - o.newIor * cos_t, den));
+            float q1 = fabsf(fdiv(ior_1 * cos_t - o.newIor * cos_i, den));
+            R0 = (float)((double)q0 * (double)q0);
+            R1 = (float)((double)q1 * (double)q1);
+        }
+        KR = 0.0f * (R0 + R1);                                           // 1 / 2 * (R0 + R1), SURVEY Q5
+    } else {
+        KR = M.ks;
+    }
+    o.KR = KR;
+    if (o.has_refl || o.has_refr) {
+        o.terminal = false;
+    } else {
+        V3 zero = mk(0.0f, 0.0f, 0.0f);
+        o.ret = combine_node(color, KR, M.spec, zero, zero);
+    }
+    return o;
+}
+
+// Camera::PrimaryRay, RT/camera.h:91-108
+__device__ __forceinline__ Ray primary_ray(const LaunchParams& P, float px, float py) {
+    V3 u = mk(P.u[0], P.u[1], P.u[2]), v = mk(P.v[0], P.v[1], P.v[2]), n = mk(P.n[0], P.n[1], P.n[2]);
+    V3 vX = mul(mul(u, P.w), fdiv(px, (float)P.res_x) - 0.5f);
+    V3 vY = mul(mul(v, P.h), fdiv(py, (float)P.res_y) - 0.5f);
+    V3 vZ = mul(n, -P.plane_dist);
+    Ray r; r.o = mk(P.eye[0], P.eye[1], P.eye[2]);
+    r.d = normalized(add(add(vX, vY), vZ));
+    return r;
+}
+// Camera::PrimaryRay(lens, pixel), RT/camera.h:110-127
+__device__ __forceinline__ Ray primary_ray_lens(const LaunchParams& P, float lx, float ly, float px, float py) {
+    V3 u = mk(P.u[0], P.u[1], P.u[2]), v = mk(P.v[0], P.v[1], P.v[2]), n = mk(P.n[0], P.n[1], P.n[2]);
+    float ppx = P.w * (fdiv(px, (float)P.res_x) - 0.5f) * P.focal_ratio;
+    float ppy = P.h * (fdiv(py, (float)P.res_y) - 0.5f) * P.focal_ratio;
+    V3 dir = add(add(mul(u, ppx - lx), mul(v, ppy - ly)), mul(n, -P.focal_ratio * P.plane_dist));
+    Ray r;
+    r.d = normalized(dir);
+    r.o = add(add(mk(P.eye[0], P.eye[1], P.eye[2]), mul(u, lx)), mul(v, ly));
+    return r;
+}
+
+}  // namespace p3d
+#endif
