@@ -101,6 +101,9 @@ typedef struct p3d_render_params {
 } p3d_render_params;
 
 #define P3D_FLAG_COUNTERS 1u     /* accumulate p3d_counters on the device (slower kernels)  */
+#define P3D_FLAG_NO_PACKET 8u    /* per-lane BVH walk even for trees small enough for the
+                                    wave-wide (packet) walk                                       */
+#define P3D_FLAG_NO_LDS_SCENE 4u /* read the scene from HBM/L2 even when it would fit in LDS    */
 #define P3D_FLAG_TREE_KERNEL 2u  /* one launch, per-lane post-order frame stack in LDS, instead
                                     of the default level-by-level wavefront schedule; results are
                                     bit-identical (also the automatic fallback when the wavefront
@@ -168,8 +171,10 @@ int p3d_get_counters(p3d_scene* scene, p3d_counters* out);
 /* Launch tuning that never changes results (0 keeps the current value): xcd_chunk =
  * consecutive 16x4-pixel tiles given to one XCD before moving to the next (1 = round robin,
  * best load balance; larger = more L2 locality per XCD for big scenes); workspace_mib = HBM
- * budget for the wavefront ray queues (default 8192; frames that need more run in bands). */
-int p3d_set_tuning(p3d_scene* scene, int32_t xcd_chunk, int32_t workspace_mib);
+ * budget for the wavefront ray queues (default 8192; frames that need more run in bands);
+ * waves_per_simd = register budget of the ray kernels expressed as resident waves per SIMD:
+ * 0 compiler default, 5 / 6 trade spilled registers for latency hiding, -1 keeps. */
+int p3d_set_tuning(p3d_scene* scene, int32_t xcd_chunk, int32_t workspace_mib, int32_t waves_per_simd);
 
 /* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the
  * scene's own stream. */

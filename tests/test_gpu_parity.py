@@ -120,13 +120,19 @@ def test_result_is_independent_of_the_bvh_shape(frames, leaf_max):
         compare(out, frames[name + "/rgb8"], frames[name + "/rgb32f"], frames[name + "/hit_id"], name)
 
 
-def test_wavefront_and_tree_schedules_are_bit_identical():
-    for name in ("c2_mount_low_256x144_d4_bvh", "c4_mount_low_96_d6_spp2", "balls_box_128_d4_bvh", "dof_64_d4_spp4"):
+def test_schedules_and_scene_placements_are_bit_identical():
+    """wavefront vs tree kernel, wave-wide vs per-lane BVH walk, scene read from its LDS copy vs from
+    HBM/L2: same bits, same ray counts."""
+    for name in ("c2_mount_low_256x144_d4_bvh", "c4_mount_low_96_d6_spp2", "balls_box_128_d4_bvh", "dof_64_d4_spp4",
+                 "balls_medium_128_d4_none"):
         a = gpu_render(CASES[name], counters=True)
-        b = gpu_render(CASES[name], counters=True, tree=True)
-        assert np.array_equal(a["rgb8"], b["rgb8"]) and np.array_equal(a["hit_id"], b["hit_id"]), name
-        assert np.array_equal(a["rgb32f"].view(np.uint32), b["rgb32f"].view(np.uint32)), name
-        assert a["counters"] == b["counters"], name
+        for kw in (dict(tree=True), dict(no_lds=True), dict(tree=True, no_lds=True), dict(no_packet=True),
+                   dict(no_packet=True, no_lds=True)):
+            b = gpu_render(CASES[name], counters=True, **kw)
+            assert np.array_equal(a["rgb8"], b["rgb8"]) and np.array_equal(a["hit_id"], b["hit_id"]), (name, kw)
+            assert np.array_equal(a["rgb32f"].view(np.uint32), b["rgb32f"].view(np.uint32)), (name, kw)
+            for k in ("closest_queries", "shadow_queries", "pixels"):      # test counts depend on the walk
+                assert a["counters"][k] == b["counters"][k], (name, kw, k)
 
 
 def test_wavefront_bands_do_not_change_the_image():

@@ -22,11 +22,16 @@ ap.add_argument("--accel", type=int, default=2)
 ap.add_argument("--leaf", type=int, default=0)
 ap.add_argument("--n", type=int, default=50)
 ap.add_argument("--tree", action="store_true")
+ap.add_argument("--occ", default="0")
+ap.add_argument("--eye", nargs=3, type=float, default=None)
+ap.add_argument("--f32", action="store_true")
 a = ap.parse_args()
 
 import torch  # noqa: E402
 hs = P.HostScene(scene_path(a.scene))
 hs.set_resolution(*a.res)
+if a.eye:
+    hs.set_eye(*a.eye)
 cam = hs.camera()
 ds = P.DeviceScene.from_host(hs, leaf_max=a.leaf)
 print("stats", ds.stats())
@@ -36,17 +41,21 @@ c = ds.counters()
 print("counters", c)
 ref = None
 for tree in ([False, True] if not a.tree else [True]):
+  for no_lds, no_packet in ((False, False), (False, True), (True, False), (True, True)):
+   if tree and not no_packet: continue
+   for occ in [int(v) for v in a.occ.split(",")]:
     for ch in [int(v) for v in a.chunks.split(",")]:
-        ds.set_tuning(xcd_chunk=ch)
+        ds.set_tuning(xcd_chunk=ch, waves_per_simd=occ)
+        kw = dict(max_depth=a.depth, accel=a.accel, tree=tree, no_lds=no_lds, no_packet=no_packet)
         for _ in range(5):
-            ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=a.depth, accel=a.accel, tree=tree)
+            ds.render_device(cam, rgb8_ptr=buf.data_ptr(), **kw)
         ds.timer_begin()
         for _ in range(a.n):
-            ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=a.depth, accel=a.accel, tree=tree)
+            ds.render_device(cam, rgb8_ptr=buf.data_ptr(), **kw)
         ms = ds.timer_end() / a.n
         img = buf.cpu().numpy()
         if ref is None:
             ref = img
-        print("%s xcd_chunk %6d: %.4f ms/frame  %.1f Mrays/s  alg %.0f GB/s  same_image=%s" % (
-            "tree     " if tree else "wavefront", ch, ms, c["rays"] / ms / 1e3,
+        print("%s %s occ %d xcd_chunk %6d: %.4f ms/frame  %.1f Mrays/s  alg %.0f GB/s  same_image=%s" % (
+            "tree     " if tree else "wavefront", ("hbm" if no_lds else "lds") + ("/lane  " if no_packet else "/packet"), occ, ch, ms, c["rays"] / ms / 1e3,
             (c["algorithmic_bytes"] + 3 * c["pixels"]) / ms / 1e6, np.array_equal(img, ref)))

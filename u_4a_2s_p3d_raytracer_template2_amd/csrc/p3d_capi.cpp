@@ -17,11 +17,12 @@
 #include "scene_flatten.h"
 
 namespace p3d {
-size_t tree_kernel_lds_bytes(const LaunchParams& P);
-size_t wavefront_lds_bytes(const LaunchParams& P);
-hipError_t launch_tree(const LaunchParams& P, bool count, hipStream_t stream);
-hipError_t launch_wf_primary(const LaunchParams& P, bool count, hipStream_t stream);
-hipError_t launch_wf_secondary(const LaunchParams& P, bool count, unsigned waves, hipStream_t stream);
+size_t tree_kernel_lds_bytes(const LaunchParams& P, bool lds);
+size_t wavefront_lds_bytes(const LaunchParams& P, bool lds);
+hipError_t launch_tree(const LaunchParams& P, bool count, bool lds, int occ, hipStream_t stream);
+hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, bool packet, int occ, hipStream_t stream);
+hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, bool packet, int occ, unsigned waves,
+                               hipStream_t stream);
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream);
 hipError_t prepare_kernels(size_t max_lds);
 hipError_t launch_deinterleave(const void* gathered, void* frame, int res_x, int res_y, int row_block,
@@ -84,16 +85,14 @@ struct RawBuf {
 struct p3d_scene {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    DevBuf<NodePair> nodes;
-    DevBuf<uint32_t> leaf_refs;
-    DevBuf<SphereRec> spheres;
-    DevBuf<PrimMeta> sphere_meta;
-    DevBuf<TriRec> tris;
-    DevBuf<BoxRec> boxes;
+    DevBuf<uint32_t> blob;              // nodes | leaf refs | spheres | sphere meta | tris | boxes | materials
+    uint32_t blob_quads = 0;
+    uint32_t off_nodes = 0, off_refs = 0, off_spheres = 0, off_sphere_meta = 0, off_tris = 0, off_boxes = 0, off_mats = 0;
     DevBuf<PlaneRec> planes;
     DevBuf<PrimMeta> plane_meta;
-    DevBuf<MaterialRec> materials;
     DevBuf<LightRec> lights;
+    size_t lds_scene_limit = 24 * 1024;  // blobs up to this size are rendered from an LDS copy
+    uint32_t packet_node_limit = 64;     // trees up to this many node pairs use the wave-wide walk
     float bg[3] = {0, 0, 0};
     uint32_t n_lights = 0, n_materials = 0;
     p3d_scene_stats stats{};
@@ -107,6 +106,7 @@ struct p3d_scene {
     bool timer_open = false;
     size_t lds_prepared = 0;
     int xcd_chunk = 1;
+    int occupancy = 0;     // 0 = compiler default register budget, else 5 / 6 / 8 waves per SIMD
 };
 
 extern "C" {
@@ -165,15 +165,28 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     s->stream = s->own_stream;
     if ((e = hipEventCreate(&s->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&s->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = s->nodes.upload(nodes)) != hipSuccess) return bail(e, "upload nodes");
-    if ((e = s->leaf_refs.upload(refs)) != hipSuccess) return bail(e, "upload leaf refs");
-    if ((e = s->spheres.upload(spheres)) != hipSuccess) return bail(e, "upload spheres");
-    if ((e = s->sphere_meta.upload(sphere_meta)) != hipSuccess) return bail(e, "upload sphere meta");
-    if ((e = s->tris.upload(tris)) != hipSuccess) return bail(e, "upload triangles");
-    if ((e = s->boxes.upload(boxes)) != hipSuccess) return bail(e, "upload boxes");
+    {   // pack the per-lane-indexed arrays into one blob of 16-byte quads
+        std::vector<uint32_t> blob;
+        auto section = [&](const void* data, size_t bytes) {
+            uint32_t off = (uint32_t)(blob.size() / 4);
+            size_t dw = (bytes + 15) / 16 * 4;
+            size_t at = blob.size();
+            blob.resize(at + std::max<size_t>(dw, 4), 0u);
+            if (bytes) memcpy(blob.data() + at, data, bytes);
+            return off;
+        };
+        s->off_nodes = section(nodes.data(), nodes.size() * sizeof(NodePair));
+        s->off_refs = section(refs.data(), refs.size() * sizeof(uint32_t));
+        s->off_spheres = section(spheres.data(), spheres.size() * sizeof(SphereRec));
+        s->off_sphere_meta = section(sphere_meta.data(), sphere_meta.size() * sizeof(PrimMeta));
+        s->off_tris = section(tris.data(), tris.size() * sizeof(TriRec));
+        s->off_boxes = section(boxes.data(), boxes.size() * sizeof(BoxRec));
+        s->off_mats = section(mats.data(), mats.size() * sizeof(MaterialRec));
+        s->blob_quads = (uint32_t)(blob.size() / 4);
+        if ((e = s->blob.upload(blob)) != hipSuccess) return bail(e, "upload scene blob");
+    }
     if ((e = s->planes.upload(planes)) != hipSuccess) return bail(e, "upload planes");
     if ((e = s->plane_meta.upload(plane_meta)) != hipSuccess) return bail(e, "upload plane meta");
-    if ((e = s->materials.upload(mats)) != hipSuccess) return bail(e, "upload materials");
     if ((e = s->lights.upload(lights)) != hipSuccess) return bail(e, "upload lights");
     if ((e = hipMalloc((void**)&s->d_counters, sizeof(DeviceCounters))) != hipSuccess) return bail(e, "alloc counters");
     if ((e = hipMemset(s->d_counters, 0, sizeof(DeviceCounters))) != hipSuccess) return bail(e, "clear counters");
@@ -184,9 +197,7 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     s->stats.n_spheres = (uint32_t)spheres.size(); s->stats.n_triangles = (uint32_t)tris.size();
     s->stats.n_boxes = (uint32_t)boxes.size(); s->stats.n_planes = (uint32_t)planes.size();
     s->stats.n_culled = 0;
-    s->stats.device_bytes = s->nodes.bytes() + s->leaf_refs.bytes() + s->spheres.bytes() + s->sphere_meta.bytes() +
-                            s->tris.bytes() + s->boxes.bytes() + s->planes.bytes() + s->plane_meta.bytes() +
-                            s->materials.bytes() + s->lights.bytes();
+    s->stats.device_bytes = s->blob.bytes() + s->planes.bytes() + s->plane_meta.bytes() + s->lights.bytes();
     *out = s;
     return P3D_OK;
 }
@@ -195,9 +206,7 @@ int p3d_scene_destroy(p3d_scene* s) {
     if (!s) return P3D_OK;
     (void)hipSetDevice(s->device);
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
-    s->nodes.release(); s->leaf_refs.release(); s->spheres.release(); s->sphere_meta.release();
-    s->tris.release(); s->boxes.release(); s->planes.release(); s->plane_meta.release();
-    s->materials.release(); s->lights.release();
+    s->blob.release(); s->planes.release(); s->plane_meta.release(); s->lights.release();
     s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release();
     for (auto& b : s->wf_rays) b.release();
     for (auto& b : s->wf_nodes) b.release();
@@ -222,12 +231,17 @@ int p3d_set_stream(p3d_scene* s, void* hip_stream) {
     return P3D_OK;
 }
 
-int p3d_set_tuning(p3d_scene* s, int32_t xcd_chunk, int32_t workspace_mib) {
+int p3d_set_tuning(p3d_scene* s, int32_t xcd_chunk, int32_t workspace_mib, int32_t waves_per_simd) {
     if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
     if (xcd_chunk < 0 || xcd_chunk > (1 << 20)) return fail(P3D_ERR_ARG, "xcd_chunk must be >= 0");
     if (workspace_mib < 0) return fail(P3D_ERR_ARG, "workspace_mib must be >= 0");
     if (xcd_chunk) s->xcd_chunk = xcd_chunk;
     if (workspace_mib) s->workspace_budget = (size_t)workspace_mib << 20;
+    if (waves_per_simd >= 0) {
+        if (waves_per_simd != 0 && waves_per_simd != 5 && waves_per_simd != 6)
+            return fail(P3D_ERR_ARG, "waves_per_simd must be 0 (default), 5 or 6");
+        s->occupancy = waves_per_simd;
+    }
     return P3D_OK;
 }
 
@@ -241,33 +255,44 @@ size_t wavefront_bytes_per_pixel(int D) {
     return b;
 }
 
+constexpr int kShards = 64;   // queue shards (power of two); spreads the slot-allocation atomics
+
 // One sample pass over one band of tile rows, level by level (see p3d_kernels.hip).
-int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, size_t band_px) {
+// shard_px = pixels a shard can own in this band (worst case), so level l holds at most
+// shard_px << (l-1) rays / nodes per shard.
+int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, bool lds, bool packet, size_t shard_px) {
     const int D = P.max_depth;
-    uint32_t* counts = (uint32_t*)s->wf_counts.p;      // [0..31] ray queue sizes, [32..63] node counts
-    HIP_TRY(hipMemsetAsync(counts, 0, 64 * sizeof(uint32_t), s->stream));
+    uint32_t* counts = (uint32_t*)s->wf_counts.p;      // [level][shard] ray counts, then node counts
+    const size_t n_counts = (size_t)2 * (kMaxDepth + 2) * kShards;
+    HIP_TRY(hipMemsetAsync(counts, 0, n_counts * sizeof(uint32_t), s->stream));
     auto rays = [&](int l) { return (l >= 2 && l <= D) ? (RayRec*)s->wf_rays[l].p : nullptr; };
     auto nodes = [&](int l) { return (l >= 1 && l <= D - 1) ? (NodeRec*)s->wf_nodes[l].p : nullptr; };
+    auto qcount = [&](int l) { return counts + (size_t)l * kShards; };
+    auto ncount = [&](int l) { return counts + (size_t)(kMaxDepth + 2 + l) * kShards; };
+    auto cap = [&](int l) { return (uint32_t)(shard_px << (l - 1)); };
+    P.wf_shards = kShards;
     P.wf_level = 1;
-    P.wf_rays_in = nullptr; P.wf_count_in = nullptr;
-    P.wf_rays_out = rays(2); P.wf_count_out = counts + 2;
-    P.wf_nodes_parent = nullptr; P.wf_nodes_self = nodes(1); P.wf_ncount_self = counts + 32 + 1;
-    HIP_TRY(launch_wf_primary(P, count, s->stream));
+    P.wf_rays_in = nullptr; P.wf_count_in = nullptr; P.wf_cap_in = 0;
+    P.wf_rays_out = rays(2); P.wf_count_out = qcount(2); P.wf_cap_out = cap(2);
+    P.wf_nodes_parent = nullptr; P.wf_ncap_parent = 0;
+    P.wf_nodes_self = nodes(1); P.wf_ncount_self = ncount(1); P.wf_ncap_self = cap(1);
+    HIP_TRY(launch_wf_primary(P, count, lds, packet, s->occupancy, s->stream));
     for (int l = 2; l <= D; l++) {
         P.wf_level = l;
-        P.wf_rays_in = rays(l); P.wf_count_in = counts + l;
-        P.wf_rays_out = rays(l + 1); P.wf_count_out = counts + l + 1;
-        P.wf_nodes_parent = nodes(l - 1); P.wf_nodes_self = nodes(l); P.wf_ncount_self = counts + 32 + l;
-        size_t cap = band_px << (l - 1);
-        unsigned waves = (unsigned)std::min<size_t>((cap + 63) / 64, kPersistentWaves);
-        HIP_TRY(launch_wf_secondary(P, count, waves, s->stream));
+        P.wf_rays_in = rays(l); P.wf_count_in = qcount(l); P.wf_cap_in = cap(l);
+        P.wf_rays_out = rays(l + 1); P.wf_count_out = qcount(l + 1); P.wf_cap_out = cap(l + 1);
+        P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = cap(l - 1);
+        P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
+        size_t total = (size_t)cap(l) * kShards;
+        unsigned waves = (unsigned)std::min<size_t>((total + 63) / 64, kPersistentWaves);
+        waves = std::max<unsigned>(kShards * 4, (waves / (kShards * 4)) * (kShards * 4));   // whole workgroups per shard
+        HIP_TRY(launch_wf_secondary(P, count, lds, packet, s->occupancy, waves, s->stream));
     }
     for (int l = D - 1; l >= 1; l--) {
         P.wf_level = l;
-        P.wf_nodes_self = nodes(l); P.wf_ncount_self = counts + 32 + l; P.wf_nodes_parent = nodes(l - 1);
-        size_t cap = band_px << (l - 1);
-        unsigned blocks = (unsigned)std::min<size_t>((cap + 255) / 256, 2048);
-        HIP_TRY(launch_wf_resolve(P, blocks, s->stream));
+        P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
+        P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = l > 1 ? cap(l - 1) : 0;
+        HIP_TRY(launch_wf_resolve(P, kShards * 4, s->stream));
     }
     return P3D_OK;
 }
@@ -290,9 +315,15 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
 
     LaunchParams P;
     memset(&P, 0, sizeof P);
-    P.nodes = s->nodes.p; P.leaf_refs = s->leaf_refs.p; P.spheres = s->spheres.p; P.sphere_meta = s->sphere_meta.p;
-    P.tris = s->tris.p; P.boxes = s->boxes.p; P.planes = s->planes.p; P.plane_meta = s->plane_meta.p;
-    P.materials = s->materials.p; P.lights = s->lights.p;
+    P.blob = s->blob.p; P.blob_quads = s->blob_quads;
+    P.off_nodes = s->off_nodes; P.off_refs = s->off_refs; P.off_spheres = s->off_spheres;
+    P.off_sphere_meta = s->off_sphere_meta; P.off_tris = s->off_tris; P.off_boxes = s->off_boxes; P.off_mats = s->off_mats;
+    P.planes = s->planes.p; P.plane_meta = s->plane_meta.p; P.lights = s->lights.p;
+    // small scenes are rendered from an LDS copy shared by the 4 waves of a 256-thread workgroup
+    const bool lds_scene = !(prm->flags & P3D_FLAG_NO_LDS_SCENE) && (size_t)s->blob_quads * 16 <= s->lds_scene_limit;
+    P.wg_waves = lds_scene ? 4 : 1;
+    // small trees are walked by the whole wave together (packet walk), large ones per lane
+    const bool packet = !(prm->flags & P3D_FLAG_NO_PACKET) && s->stats.n_nodes <= s->packet_node_limit;
     P.n_planes = s->stats.n_planes; P.n_lights = s->n_lights; P.n_materials = s->n_materials;
     P.trav_stack_entries = std::max<uint32_t>(s->stats.max_depth + 1, 2);
     memcpy(P.bg, s->bg, sizeof P.bg);
@@ -303,7 +334,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     P.max_depth = prm->max_depth; P.accel = prm->accel; P.spp = prm->spp;
     P.row_block = row_block; P.rank = rank; P.world = world;
     P.local_rows = p3d_local_rows(cam->res_y, row_block, world);
-    const int tile_rows = 4 * kWavesPerGroup;
+    const int tile_rows = 4 * P.wg_waves;
     P.tiles_x = (cam->res_x + 15) / 16; P.tiles_y = P.local_rows / tile_rows;
     P.n_tiles = P.tiles_x * P.tiles_y;
     P.xcd_chunk = s->xcd_chunk > 0 ? s->xcd_chunk : 1;
@@ -315,13 +346,13 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
 
     const bool tree_requested = (prm->flags & P3D_FLAG_TREE_KERNEL) != 0;
     // wavefront bands: worst-case queues for a band of tile rows must fit the workspace budget
-    const size_t tile_row_px = (size_t)P.tiles_x * 64 * kWavesPerGroup;
+    const size_t tile_row_px = (size_t)P.tiles_x * 64 * P.wg_waves;
     const size_t wf_bpp = wavefront_bytes_per_pixel(prm->max_depth) + (prm->spp > 0 ? 12 : 0);
     size_t band_tile_rows = wf_bpp ? s->workspace_budget / (wf_bpp * tile_row_px) : (size_t)P.tiles_y;
     if (wf_bpp == 0) band_tile_rows = (size_t)P.tiles_y;
     band_tile_rows = std::min<size_t>(band_tile_rows, (size_t)P.tiles_y);
     const bool use_tree = tree_requested || band_tile_rows == 0;
-    size_t lds = use_tree ? tree_kernel_lds_bytes(P) : wavefront_lds_bytes(P);
+    size_t lds = use_tree ? tree_kernel_lds_bytes(P, lds_scene) : wavefront_lds_bytes(P, lds_scene);
     if (lds > kMaxLdsBytes) return fail(P3D_ERR_LIMIT, "BVH depth / max_depth need more LDS than a CU has");
     if (lds > 64 * 1024 && !s->lds_prepared) {
         HIP_TRY(prepare_kernels(kMaxLdsBytes));
@@ -350,13 +381,15 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     P.wf_nsamples = prm->spp > 0 ? prm->spp * prm->spp : 1;
     if (use_tree) {
         P.wf_tile_row0 = 0; P.wf_tile_rows = P.tiles_y;
-        HIP_TRY(launch_tree(P, count, s->stream));
+        HIP_TRY(launch_tree(P, count, lds_scene, s->occupancy, s->stream));
     } else {
         const int D = prm->max_depth;
-        const size_t band_px = band_tile_rows * tile_row_px;
-        for (int l = 2; l <= D; l++) HIP_TRY(s->wf_rays[l].ensure((band_px << (l - 1)) * sizeof(RayRec)));
-        for (int l = 1; l <= D - 1; l++) HIP_TRY(s->wf_nodes[l].ensure((band_px << (l - 1)) * sizeof(NodeRec)));
-        HIP_TRY(s->wf_counts.ensure(64 * sizeof(uint32_t)));
+        // a shard owns every kShards-th tile of the band
+        const size_t band_tiles = band_tile_rows * (size_t)P.tiles_x;
+        const size_t shard_px = ((band_tiles + kShards - 1) / kShards) * 64 * P.wg_waves;
+        for (int l = 2; l <= D; l++) HIP_TRY(s->wf_rays[l].ensure((shard_px << (l - 1)) * kShards * sizeof(RayRec)));
+        for (int l = 1; l <= D - 1; l++) HIP_TRY(s->wf_nodes[l].ensure((shard_px << (l - 1)) * kShards * sizeof(NodeRec)));
+        HIP_TRY(s->wf_counts.ensure((size_t)2 * (kMaxDepth + 2) * kShards * sizeof(uint32_t)));
         if (prm->spp > 0) { HIP_TRY(s->wf_accum.ensure(npx * 12)); P.wf_accum = (float*)s->wf_accum.p; }
         // samples outermost: a pixel's clamped sample colours are summed in sample order
         for (int smp = 0; smp < P.wf_nsamples; smp++) {
@@ -368,7 +401,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
                 B.n_tiles = B.tiles_x * B.wf_tile_rows;
                 int chunks = (B.n_tiles + B.xcd_chunk - 1) / B.xcd_chunk;
                 B.grid_blocks = ((chunks + 7) / 8) * 8 * B.xcd_chunk;
-                int rc = run_wavefront_pass(s, B, count, band_px);
+                int rc = run_wavefront_pass(s, B, count, lds_scene, packet, shard_px);
                 if (rc) return rc;
             }
         }

@@ -57,16 +57,15 @@ struct DeviceCounters {
 
 // Everything a render launch needs, passed by value (lands in SGPRs / kernarg segment).
 struct LaunchParams {
-    // scene
-    const NodePair*    nodes;
-    const uint32_t*    leaf_refs;
-    const SphereRec*   spheres;
-    const PrimMeta*    sphere_meta;
-    const TriRec*      tris;
-    const BoxRec*      boxes;
+    // scene: one blob of 16-byte quads holding every per-lane-indexed array (nodes, leaf refs,
+    // spheres, sphere meta, triangles, boxes, materials; section offsets in quads), so that a
+    // small scene can be copied into LDS with one loop; wave-uniform arrays stay separate
+    const void*        blob;
+    uint32_t           blob_quads;
+    uint32_t           off_nodes, off_refs, off_spheres, off_sphere_meta, off_tris, off_boxes, off_mats;
+    int32_t            wg_waves;          // waves per workgroup of this launch (1, or 4 with an LDS scene)
     const PlaneRec*    planes;
     const PrimMeta*    plane_meta;
-    const MaterialRec* materials;
     const LightRec*    lights;
     uint32_t n_planes, n_lights, n_materials, trav_stack_entries;
     float bg[3];
@@ -86,6 +85,12 @@ struct LaunchParams {
     int32_t wf_level;              // tree level this launch traces / resolves (1 = primary rays)
     int32_t wf_sample, wf_nsamples;
     int32_t wf_tile_row0, wf_tile_rows;      // band of 16x4-tile rows handled by this pass
+    // The queues are split into wf_shards independent shards (tile t -> shard t % wf_shards; a
+    // ray stays in its pixel's shard for its whole tree) so that the per-wave slot allocation
+    // atomics spread over wf_shards counters instead of serialising on one word.  Pointers below
+    // address shard 0; shard s is at + s * cap entries / + s counters.
+    int32_t wf_shards;
+    uint32_t wf_cap_in, wf_cap_out, wf_ncap_parent, wf_ncap_self;    // entries per shard
     const RayRec* wf_rays_in;  const uint32_t* wf_count_in;      // level wf_level queue
     RayRec* wf_rays_out;       uint32_t* wf_count_out;           // level wf_level + 1 queue
     NodeRec* wf_nodes_parent;                                     // level wf_level - 1 nodes

@@ -71,7 +71,7 @@ __device__ __forceinline__ void sink_sample(const LaunchParams& P, size_t p, V3 
 }
 
 // tile -> pixel.  Returns false for lanes outside the image.
-__device__ __forceinline__ bool tile_pixel(const LaunchParams& P, int& x, int& y, int& row) {
+__device__ __forceinline__ bool tile_pixel(const LaunchParams& P, int& x, int& y, int& row, int* tile_out = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // XCD-aware tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
     // share one, each XCD has its own L2), so XCD k is given CHUNKS of xcd_chunk consecutive
@@ -81,10 +81,11 @@ __device__ __forceinline__ bool tile_pixel(const LaunchParams& P, int& x, int& y
     const int j = bid >> 3;
     const int tile = ((j / P.xcd_chunk) * 8 + (bid & 7)) * P.xcd_chunk + (j % P.xcd_chunk);
     x = 0; y = 0; row = 0;
+    if (tile_out) *tile_out = tile;
     if (tile >= P.n_tiles) return false;
     const int tx = tile % P.tiles_x, ty = P.wf_tile_row0 + tile / P.tiles_x;
     x = tx * 16 + (lane & 15);
-    row = ty * (kWavesPerGroup * 4) + (lane >> 4) + wave * 4;     // row in the compact local buffer
+    row = ty * (P.wg_waves * 4) + (lane >> 4) + wave * 4;         // row in the compact local buffer
     const int blk = row / P.row_block;
     y = (blk * P.world + P.rank) * P.row_block + (row - blk * P.row_block);
     return x < P.res_x && y < P.res_y;
@@ -98,20 +99,39 @@ __device__ __forceinline__ Ray camera_ray(const LaunchParams& P, int x, int y, i
 }
 
 // ------------------------------------------------------------------ WAVEFRONT schedule
+// One shard's slice of the level queues (see LaunchParams::wf_shards).
+struct Shard {
+    const RayRec* rays_in; uint32_t count_in;
+    RayRec* rays_out; uint32_t* count_out;
+    NodeRec* nodes_parent; NodeRec* nodes_self; uint32_t* ncount_self;
+};
+__device__ __forceinline__ Shard shard_of(const LaunchParams& P, uint32_t s) {
+    Shard h;
+    h.rays_in = P.wf_rays_in ? P.wf_rays_in + (size_t)s * P.wf_cap_in : nullptr;
+    h.count_in = P.wf_count_in ? P.wf_count_in[s] : 0u;
+    h.rays_out = P.wf_rays_out ? P.wf_rays_out + (size_t)s * P.wf_cap_out : nullptr;
+    h.count_out = P.wf_count_out + s;
+    h.nodes_parent = P.wf_nodes_parent ? P.wf_nodes_parent + (size_t)s * P.wf_ncap_parent : nullptr;
+    h.nodes_self = P.wf_nodes_self ? P.wf_nodes_self + (size_t)s * P.wf_ncap_self : nullptr;
+    h.ncount_self = P.wf_ncount_self + s;
+    return h;
+}
+
 // Hand a finished node's return value to whoever waits for it.
-__device__ __forceinline__ void deliver(const LaunchParams& P, int level, uint32_t link, V3 ret) {
+__device__ __forceinline__ void deliver(const LaunchParams& P, const Shard& sh, int level, uint32_t link, V3 ret) {
     if (level == 1) { sink_sample(P, (size_t)link, ret); return; }
-    NodeRec* parent = P.wf_nodes_parent + (link & ~kLinkRefr);
+    NodeRec* parent = sh.nodes_parent + (link & ~kLinkRefr);
     float* dst = (link & kLinkRefr) ? parent->refr_ret : parent->refl_ret;
     dst[0] = ret.x; dst[1] = ret.y; dst[2] = ret.z;
 }
 
-// Park a node with children and queue its child rays.  Must be reached by ALL 64 lanes of the
-// wave (converged): slots are handed out with ballot + mbcnt prefix sums, one atomic per wave.
-__device__ __forceinline__ void emit(const LaunchParams& P, int level, bool valid, uint32_t link, float ior_1,
-                                     const NodeOut& o) {
+// Park a node with children and queue its child rays.  Must be reached by ALL lanes of the
+// wave together (converged): slots are handed out with ballot + mbcnt prefix sums and one
+// atomic per counter per wave.
+__device__ __forceinline__ void emit(const LaunchParams& P, const Shard& sh, int level, bool valid, uint32_t link,
+                                     float ior_1, const NodeOut& o) {
     const int lane = threadIdx.x & 63;
-    if (valid && o.terminal) deliver(P, level, link, o.ret);
+    if (valid && o.terminal) deliver(P, sh, level, link, o.ret);
     const bool parks = valid && !o.terminal;
     const uint64_t m_node = __ballot(parks);
     if (m_node == 0) return;                                   // wave-uniform
@@ -119,94 +139,144 @@ __device__ __forceinline__ void emit(const LaunchParams& P, int level, bool vali
     const uint64_t m_refr = __ballot(parks && o.has_refr);
     const uint32_t n_refl = (uint32_t)__popcll(m_refl), n_refr = (uint32_t)__popcll(m_refr);
     uint32_t node_base = 0, ray_base = 0;
-    if (lane == 0) {
-        node_base = atomicAdd(P.wf_ncount_self, (uint32_t)__popcll(m_node));
-        ray_base = atomicAdd(P.wf_count_out, n_refl + n_refr);
+    if (lane == (int)__builtin_ctzll(m_node)) {
+        node_base = atomicAdd(sh.ncount_self, (uint32_t)__popcll(m_node));
+        ray_base = atomicAdd(sh.count_out, n_refl + n_refr);
     }
-    node_base = __shfl(node_base, 0);
-    ray_base = __shfl(ray_base, 0);
+    node_base = __shfl(node_base, (int)__builtin_ctzll(m_node));
+    ray_base = __shfl(ray_base, (int)__builtin_ctzll(m_node));
     if (!parks) return;
     const uint32_t my_node = node_base + lane_rank(m_node);
-    float4* nd = reinterpret_cast<float4*>(P.wf_nodes_self + my_node);
+    float4* nd = reinterpret_cast<float4*>(sh.nodes_self + my_node);
     nd[0] = make_float4(o.color.x, o.color.y, o.color.z, o.KR);
     nd[1] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(o.mat));
     nd[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(link));
     if (o.has_refl) {                                           // reflection child keeps ior_1
-        float4* rq = reinterpret_cast<float4*>(P.wf_rays_out + ray_base + lane_rank(m_refl));
+        float4* rq = reinterpret_cast<float4*>(sh.rays_out + ray_base + lane_rank(m_refl));
         rq[0] = make_float4(o.refl.o.x, o.refl.o.y, o.refl.o.z, ior_1);
         rq[1] = make_float4(o.refl.d.x, o.refl.d.y, o.refl.d.z, __uint_as_float(my_node));
     }
     if (o.has_refr) {
-        float4* rq = reinterpret_cast<float4*>(P.wf_rays_out + ray_base + n_refl + lane_rank(m_refr));
+        float4* rq = reinterpret_cast<float4*>(sh.rays_out + ray_base + n_refl + lane_rank(m_refr));
         rq[0] = make_float4(o.refr.o.x, o.refr.o.y, o.refr.o.z, o.newIor);
         rq[1] = make_float4(o.refr.d.x, o.refr.d.y, o.refr.d.z, __uint_as_float(my_node | kLinkRefr));
     }
 }
 
-__device__ __forceinline__ TravStack wave_stack(uint32_t* lds) {
-    TravStack st;
-    st.base = reinterpret_cast<uint2*>(lds) + (threadIdx.x & 63);
-    return st;
+// Scene view of this launch.  LDS variant: the workgroup first copies the blob into LDS (all
+// threads, then one barrier -- the only barrier of the launch; call before any early exit).
+template <bool LDS> struct View;
+template <> struct View<false> {
+    typedef GlobalScene type;
+    static __device__ __forceinline__ GlobalScene make(const LaunchParams& P) {
+        GlobalScene g; g.q = reinterpret_cast<const float4*>(P.blob);
+        g.o = SceneOffsets{P.off_nodes, P.off_refs, P.off_spheres, P.off_sphere_meta, P.off_tris, P.off_boxes, P.off_mats};
+        return g;
+    }
+    static __device__ __forceinline__ uint32_t scene_dwords(const LaunchParams&) { return 0; }
+};
+template <> struct View<true> {
+    typedef LdsScene type;
+    static __device__ __forceinline__ LdsScene make(const LaunchParams& P) {
+        const float4* src = reinterpret_cast<const float4*>(P.blob);
+        float4* dst = reinterpret_cast<float4*>(p3d_lds);
+        for (uint32_t i = threadIdx.x; i < P.blob_quads; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        LdsScene l;
+        l.o = SceneOffsets{P.off_nodes, P.off_refs, P.off_spheres, P.off_sphere_meta, P.off_tris, P.off_boxes, P.off_mats};
+        return l;
+    }
+    static __device__ __forceinline__ uint32_t scene_dwords(const LaunchParams& P) { return P.blob_quads * 4; }
+};
+
+// this wave's traversal stack: after the (optional) scene copy, one region per wave
+template <bool LDS>
+__device__ __forceinline__ TravCtx wave_stack(const LaunchParams& P, uint32_t extra_dwords_per_wave, uint32_t** wave_base = nullptr) {
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t* base = p3d_lds + View<LDS>::scene_dwords(P) + wave * (P.trav_stack_entries * 128 + extra_dwords_per_wave);
+    if (wave_base) *wave_base = base;
+    TravCtx tc;
+    tc.lane.base = reinterpret_cast<uint2*>(base) + (threadIdx.x & 63);
+    tc.wave.base = reinterpret_cast<int32_t*>(base);     // the two walks never run in the same launch
+    return tc;
 }
 
 // level 1: camera rays of one sample pass over a band of tiles
-template <bool COUNT>
-__global__ __launch_bounds__(64) void wf_primary_kernel(const LaunchParams P) {
-    extern __shared__ uint32_t lds[];
-    int x, y, row;
-    const bool valid = tile_pixel(P, x, y, row);
+// OCC = requested waves per SIMD (amdgpu_waves_per_eu): caps the VGPR allocation so that more
+// waves hide each other's latency, at the price of a few spilled registers.  Selected at run
+// time by p3d_set_tuning(); never changes results.
+#define P3D_OCC(OCC) __attribute__((amdgpu_waves_per_eu(OCC, 8)))
+
+template <bool COUNT, bool LDS, bool PACKET, int OCC>
+__global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel(const LaunchParams P) {
+    const typename View<LDS>::type sv = View<LDS>::make(P);
+    int x, y, row, tile;
+    const bool valid = tile_pixel(P, x, y, row, &tile);
     if (__ballot(valid) == 0) return;
-    TravStack st = wave_stack(lds);
+    const Shard sh = shard_of(P, (uint32_t)tile % (uint32_t)P.wf_shards);
+    const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
-    NodeOut o;
-    o.terminal = true; o.has_refl = o.has_refr = false;
     const size_t p = (size_t)row * P.res_x + x;
-    if (valid) {
-        Ray ray = camera_ray(P, x, y, P.wf_sample);
-        Hit h = closest_hit<COUNT>(P, ray, st, ctr);
-        if (P.hit_id && P.wf_sample == 0) P.hit_id[p] = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid;
-        o = shade_hit<COUNT>(P, ray, h, 1, 1.0f, st, ctr);
-    }
-    emit(P, 1, valid, (uint32_t)p, 1.0f, o);
+    Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
+    if (valid) ray = camera_ray(P, x, y, P.wf_sample);
+    const Hit h = find_closest<COUNT, PACKET>(P, sv, ray, valid, tc, ctr);
+    if (valid && P.hit_id && P.wf_sample == 0) P.hit_id[p] = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid;
+    const NodeOut o = shade_hit<COUNT, PACKET>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr);
+    emit(P, sh, 1, valid, (uint32_t)p, 1.0f, o);
     if (valid) flush_counters<COUNT>(P, ctr, P.wf_sample == 0 ? 1u : 0u);
 }
 
 // level >= 2: one queued ray per lane, persistent waves striding over the queue
-template <bool COUNT>
-__global__ __launch_bounds__(64) void wf_secondary_kernel(const LaunchParams P) {
-    extern __shared__ uint32_t lds[];
-    const uint32_t count = *P.wf_count_in;
+template <bool COUNT, bool LDS, bool PACKET, int OCC>
+__global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kernel(const LaunchParams P) {
+    // wave g works on shard g % S; the (gridwaves / S) waves of a shard stride over its queue
+    const uint32_t S = (uint32_t)P.wf_shards;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t per_shard = n_waves / S;
+    {   // workgroup-uniform early exit (before the scene copy's barrier): nothing queued for any of
+        // this workgroup's waves
+        const uint32_t w0 = (blockIdx.x * blockDim.x) >> 6, nw = blockDim.x >> 6;
+        bool any = false;
+        for (uint32_t w = w0; w < w0 + nw; w++)
+            if ((w / S) * 64u < P.wf_count_in[w % S]) any = true;
+        if (!any) return;
+    }
+    const typename View<LDS>::type sv = View<LDS>::make(P);
+    const Shard sh = shard_of(P, wave_id % S);
     const int lane = threadIdx.x & 63;
-    TravStack st = wave_stack(lds);
+    const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) {
+    for (uint32_t base = (wave_id / S) * 64u; base < sh.count_in; base += per_shard * 64u) {
         const uint32_t i = base + lane;
-        const bool valid = i < count;
-        NodeOut o;
-        o.terminal = true; o.has_refl = o.has_refr = false;
+        const bool valid = i < sh.count_in;
         uint32_t link = 0; float ior_1 = 1.0f;
+        Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
         if (valid) {
-            const float4* rq = reinterpret_cast<const float4*>(P.wf_rays_in + i);
+            const float4* rq = reinterpret_cast<const float4*>(sh.rays_in + i);
             float4 a = rq[0], b = rq[1];
-            Ray ray; ray.o = mk(a.x, a.y, a.z); ray.d = mk(b.x, b.y, b.z);
+            ray.o = mk(a.x, a.y, a.z); ray.d = mk(b.x, b.y, b.z);
             ior_1 = a.w; link = __float_as_uint(b.w);
-            Hit h = closest_hit<COUNT>(P, ray, st, ctr);
-            o = shade_hit<COUNT>(P, ray, h, P.wf_level, ior_1, st, ctr);
         }
-        emit(P, P.wf_level, valid, link, ior_1, o);
+        const Hit h = find_closest<COUNT, PACKET>(P, sv, ray, valid, tc, ctr);
+        const NodeOut o = shade_hit<COUNT, PACKET>(P, sv, ray, h, valid, P.wf_level, ior_1, tc, ctr);
+        emit(P, sh, P.wf_level, valid, link, ior_1, o);
     }
     flush_counters<COUNT>(P, ctr, 0u);
 }
 
 // walk one level back up: node = color + (refl_ret*KR*spec + refr_ret*(1-KR)), RT/main.cpp:719
 __global__ __launch_bounds__(256) void wf_resolve_kernel(const LaunchParams P) {
-    const uint32_t count = *P.wf_ncount_self;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const float4* nd = reinterpret_cast<const float4*>(P.wf_nodes_self + i);
+    const uint32_t S = (uint32_t)P.wf_shards;
+    const Shard sh = shard_of(P, blockIdx.x % S);
+    const uint32_t count = *sh.ncount_self;
+    const uint32_t per_shard = gridDim.x / S;
+    const GlobalScene gv = View<false>::make(P);
+    for (uint32_t i = (blockIdx.x / S) * blockDim.x + threadIdx.x; i < count; i += per_shard * blockDim.x) {
+        const float4* nd = reinterpret_cast<const float4*>(sh.nodes_self + i);
         float4 a = nd[0], b = nd[1], c = nd[2];
-        Mtl M = load_material(P, __float_as_uint(b.w));
+        Mtl M = load_material(gv, __float_as_uint(b.w));
         V3 ret = combine_node(mk(a.x, a.y, a.z), a.w, M.spec, mk(b.x, b.y, b.z), mk(c.x, c.y, c.z));
-        deliver(P, P.wf_level, __float_as_uint(c.w), ret);
+        deliver(P, sh, P.wf_level, __float_as_uint(c.w), ret);
     }
 }
 
@@ -231,8 +301,8 @@ enum { FR_C = 0, FR_KR = 3, FR_META = 4, FR_A = 5, FR_RD = 8, FR_IOR = 11 };
 #define FR_WAIT_REFR 0x80000000u
 
 // One primary ray's whole tree: rayTracing(ray, 1, 1.0) of RT/main.cpp:530-721, iterative.
-template <bool COUNT>
-__device__ __forceinline__ V3 trace_tree(const LaunchParams& P, Ray ray, TravStack st, Frames fr,
+template <bool COUNT, class SV>
+__device__ __forceinline__ V3 trace_tree(const LaunchParams& P, const SV& sv, Ray ray, const TravCtx& tc, Frames fr,
                                          int32_t& primary_hit, Ctr& ctr) {
     int fsp = 0;              // frames on the stack == depth - 1
     float ior_1 = 1.0f;
@@ -240,9 +310,9 @@ __device__ __forceinline__ V3 trace_tree(const LaunchParams& P, Ray ray, TravSta
     V3 ret = mk(0.0f, 0.0f, 0.0f);
     const V3 zero = mk(0.0f, 0.0f, 0.0f);
     for (;;) {
-        Hit h = closest_hit<COUNT>(P, ray, st, ctr);
+        Hit h = closest_hit<COUNT>(P, sv, ray, tc.lane, ctr);
         if (first) { primary_hit = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid; first = false; }
-        NodeOut o = shade_hit<COUNT>(P, ray, h, fsp + 1, ior_1, st, ctr);
+        NodeOut o = shade_hit<COUNT, false>(P, sv, ray, h, true, fsp + 1, ior_1, tc, ctr);
         if (!o.terminal) {
             fr.put3(fsp, FR_C, o.color);
             fr.f(fsp, FR_KR) = __float_as_uint(o.KR);
@@ -253,7 +323,7 @@ __device__ __forceinline__ V3 trace_tree(const LaunchParams& P, Ray ray, TravSta
                 fr.f(fsp, FR_IOR) = __float_as_uint(o.newIor);
                 ray = o.refl;                                    // ior_1 unchanged
             } else {
-                Mtl M = load_material(P, o.mat);
+                Mtl M = load_material(sv, o.mat);
                 fr.f(fsp, FR_META) = o.mat | FR_WAIT_REFR;
                 fr.put3(fsp, FR_A, cmul(mul(zero, o.KR), M.spec));
                 ray = o.refr; ior_1 = o.newIor;
@@ -270,7 +340,7 @@ __device__ __forceinline__ V3 trace_tree(const LaunchParams& P, Ray ray, TravSta
             V3 C = fr.get3(k, FR_C);
             float KR = __uint_as_float(fr.f(k, FR_KR));
             if (!(meta & FR_WAIT_REFR)) {
-                Mtl M = load_material(P, meta & 0x3FFFFFFFu);
+                Mtl M = load_material(sv, meta & 0x3FFFFFFFu);
                 V3 A = cmul(mul(ret, KR), M.spec);
                 if (meta & FR_HAS_REFR) {
                     ray.o = fr.get3(k, FR_A);
@@ -292,27 +362,27 @@ __device__ __forceinline__ V3 trace_tree(const LaunchParams& P, Ray ray, TravSta
     }
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(kWavesPerGroup * 64) void whitted_tree_kernel(const LaunchParams P) {
-    extern __shared__ uint32_t lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+template <bool COUNT, bool LDS, int OCC>
+__global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kernel(const LaunchParams P) {
+    const typename View<LDS>::type sv = View<LDS>::make(P);
+    const int lane = threadIdx.x & 63;
     int x, y, row;
     if (!tile_pixel(P, x, y, row)) return;               // no barriers below: early exit is safe
-    const int wave_dwords = P.trav_stack_entries * 128 + (P.max_depth > 1 ? (P.max_depth - 1) : 1) * 12 * 64;
-    uint32_t* wbase = lds + wave * wave_dwords;
-    TravStack st; st.base = reinterpret_cast<uint2*>(wbase) + lane;
+    const uint32_t frame_dwords = (uint32_t)(P.max_depth > 1 ? (P.max_depth - 1) : 1) * 12 * 64;
+    uint32_t* wbase;
+    const TravCtx st = wave_stack<LDS>(P, frame_dwords, &wbase);
     Frames fr; fr.base = wbase + P.trav_stack_entries * 128 + lane;
 
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
     V3 color = mk(0.0f, 0.0f, 0.0f);
     int32_t hid = -1;
     if (P.spp == 0) {                                    // RT/main.cpp:756-775
-        color = clampc(trace_tree<COUNT>(P, camera_ray(P, x, y, 0), st, fr, hid, ctr));
+        color = clampc(trace_tree<COUNT>(P, sv, camera_ray(P, x, y, 0), st, fr, hid, ctr));
     } else {                                             // RT/main.cpp:776-801
         const int ns = P.spp * P.spp;
         for (int s = 0; s < ns; s++) {
             int32_t h2 = -1;
-            V3 c = clampc(trace_tree<COUNT>(P, camera_ray(P, x, y, s), st, fr, h2, ctr));
+            V3 c = clampc(trace_tree<COUNT>(P, sv, camera_ray(P, x, y, s), st, fr, h2, ctr));
             color = add(color, c);
             if (s == 0) hid = h2;
         }
@@ -386,32 +456,63 @@ __global__ void debug_intersect_kernel(uint32_t n, const uint32_t* type, const f
 }
 
 // ------------------------------------------------------------------ launchers (host)
-size_t tree_kernel_lds_bytes(const LaunchParams& P) {
+static size_t scene_lds_bytes(const LaunchParams& P, bool lds) { return lds ? (size_t)P.blob_quads * 16 : 0; }
+size_t tree_kernel_lds_bytes(const LaunchParams& P, bool lds) {
     int frames = P.max_depth > 1 ? (P.max_depth - 1) : 1;
     size_t wave_dwords = (size_t)P.trav_stack_entries * 128 + (size_t)frames * 12 * 64;
-    return wave_dwords * 4 * kWavesPerGroup;
+    return scene_lds_bytes(P, lds) + wave_dwords * 4 * P.wg_waves;
 }
-size_t wavefront_lds_bytes(const LaunchParams& P) { return (size_t)P.trav_stack_entries * 512; }
+size_t wavefront_lds_bytes(const LaunchParams& P, bool lds) {
+    return scene_lds_bytes(P, lds) + (size_t)P.trav_stack_entries * 512 * P.wg_waves;
+}
 
-hipError_t launch_tree(const LaunchParams& P, bool count, hipStream_t stream) {
-    size_t lds = tree_kernel_lds_bytes(P);
-    dim3 grid((unsigned)P.grid_blocks), block(kWavesPerGroup * 64);
-    if (count) hipLaunchKernelGGL(whitted_tree_kernel<true>, grid, block, lds, stream, P);
-    else hipLaunchKernelGGL(whitted_tree_kernel<false>, grid, block, lds, stream, P);
+// counting builds always use the default register budget; timed builds pick OCC
+#define P3D_LAUNCH_OCC(KERNEL, occ, grid, block, shmem, stream, P, ...)                               \
+    do {                                                                                             \
+        switch (occ) {                                                                               \
+        case 5: hipLaunchKernelGGL((KERNEL<false, __VA_ARGS__, 5>), grid, block, shmem, stream, P); break;  \
+        case 6: hipLaunchKernelGGL((KERNEL<false, __VA_ARGS__, 6>), grid, block, shmem, stream, P); break;  \
+        default: hipLaunchKernelGGL((KERNEL<false, __VA_ARGS__, 1>), grid, block, shmem, stream, P); break; \
+        }                                                                                            \
+    } while (0)
+
+hipError_t launch_tree(const LaunchParams& P, bool count, bool lds, int occ, hipStream_t stream) {
+    dim3 grid((unsigned)P.grid_blocks), block(64 * P.wg_waves);
+    size_t shmem = tree_kernel_lds_bytes(P, lds);
+    if (count) {
+        if (lds) hipLaunchKernelGGL((whitted_tree_kernel<true, true, 1>), grid, block, shmem, stream, P);
+        else hipLaunchKernelGGL((whitted_tree_kernel<true, false, 1>), grid, block, shmem, stream, P);
+    } else if (lds) P3D_LAUNCH_OCC(whitted_tree_kernel, occ, grid, block, shmem, stream, P, true);
+    else P3D_LAUNCH_OCC(whitted_tree_kernel, occ, grid, block, shmem, stream, P, false);
     return hipGetLastError();
 }
-hipError_t launch_wf_primary(const LaunchParams& P, bool count, hipStream_t stream) {
-    size_t lds = wavefront_lds_bytes(P);
-    dim3 grid((unsigned)P.grid_blocks), block(64);
-    if (count) hipLaunchKernelGGL(wf_primary_kernel<true>, grid, block, lds, stream, P);
-    else hipLaunchKernelGGL(wf_primary_kernel<false>, grid, block, lds, stream, P);
+
+// wavefront level kernels: {count} x {scene in LDS} x {packet walk}
+#define P3D_LAUNCH_WF(KERNEL, count, lds, packet, occ, grid, block, shmem, stream, P)                 \
+    do {                                                                                             \
+        if (count) {                                                                                 \
+            if (lds) { if (packet) hipLaunchKernelGGL((KERNEL<true, true, true, 1>), grid, block, shmem, stream, P);   \
+                       else hipLaunchKernelGGL((KERNEL<true, true, false, 1>), grid, block, shmem, stream, P); }       \
+            else { if (packet) hipLaunchKernelGGL((KERNEL<true, false, true, 1>), grid, block, shmem, stream, P);      \
+                   else hipLaunchKernelGGL((KERNEL<true, false, false, 1>), grid, block, shmem, stream, P); }          \
+        } else if (lds) {                                                                            \
+            if (packet) P3D_LAUNCH_OCC(KERNEL, occ, grid, block, shmem, stream, P, true, true);      \
+            else P3D_LAUNCH_OCC(KERNEL, occ, grid, block, shmem, stream, P, true, false);            \
+        } else {                                                                                     \
+            if (packet) P3D_LAUNCH_OCC(KERNEL, occ, grid, block, shmem, stream, P, false, true);     \
+            else P3D_LAUNCH_OCC(KERNEL, occ, grid, block, shmem, stream, P, false, false);           \
+        }                                                                                            \
+    } while (0)
+
+hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, bool packet, int occ, hipStream_t stream) {
+    dim3 grid((unsigned)P.grid_blocks), block(64 * P.wg_waves);
+    P3D_LAUNCH_WF(wf_primary_kernel, count, lds, packet, occ, grid, block, wavefront_lds_bytes(P, lds), stream, P);
     return hipGetLastError();
 }
-hipError_t launch_wf_secondary(const LaunchParams& P, bool count, unsigned waves, hipStream_t stream) {
-    size_t lds = wavefront_lds_bytes(P);
-    dim3 grid(waves), block(64);
-    if (count) hipLaunchKernelGGL(wf_secondary_kernel<true>, grid, block, lds, stream, P);
-    else hipLaunchKernelGGL(wf_secondary_kernel<false>, grid, block, lds, stream, P);
+hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, bool packet, int occ, unsigned waves,
+                               hipStream_t stream) {
+    dim3 grid((waves + P.wg_waves - 1) / P.wg_waves), block(64 * P.wg_waves);
+    P3D_LAUNCH_WF(wf_secondary_kernel, count, lds, packet, occ, grid, block, wavefront_lds_bytes(P, lds), stream, P);
     return hipGetLastError();
 }
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream) {
@@ -420,12 +521,11 @@ hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t
 }
 
 hipError_t prepare_kernels(size_t max_lds) {
-    const void* fns[] = {reinterpret_cast<const void*>(whitted_tree_kernel<true>),
-                         reinterpret_cast<const void*>(whitted_tree_kernel<false>),
-                         reinterpret_cast<const void*>(wf_primary_kernel<true>),
-                         reinterpret_cast<const void*>(wf_primary_kernel<false>),
-                         reinterpret_cast<const void*>(wf_secondary_kernel<true>),
-                         reinterpret_cast<const void*>(wf_secondary_kernel<false>)};
+    // only the tree kernel without an LDS scene copy can need more than the 64 KiB default
+    const void* fns[] = {reinterpret_cast<const void*>(whitted_tree_kernel<true, false, 1>),
+                         reinterpret_cast<const void*>(whitted_tree_kernel<false, false, 1>),
+                         reinterpret_cast<const void*>(whitted_tree_kernel<false, false, 5>),
+                         reinterpret_cast<const void*>(whitted_tree_kernel<false, false, 6>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
         if (e != hipSuccess) return e;

@@ -11,22 +11,23 @@
 namespace p3d {
 
 // getNormal(point).normalize() of the hit primitive (RT/main.cpp:587-589)
-__device__ __forceinline__ V3 prim_normal(const LaunchParams& P, uint32_t ref, const Ray& r, V3 point) {
+template <class SV>
+__device__ __forceinline__ V3 prim_normal(const LaunchParams& P, const SV& sv, uint32_t ref, const Ray& r, V3 point) {
     uint32_t kind = ref >> kRefKindShift, idx = ref & kRefIndexMask;
     if (kind == 0u) {                                                   // RT/scene.cpp:174-178
-        float4 s = *reinterpret_cast<const float4*>(P.spheres + idx);
+        float4 s = sv_sphere(sv, idx);
         V3 n = normalized(sub(point, mk(s.x, s.y, s.z)));
         return normalized(n);
     } else if (kind == 1u) {                                            // RT/scene.cpp:10-25,46-49
-        const float4* tp = reinterpret_cast<const float4*>(P.tris + idx);
-        float4 b = tp[1], c = tp[2];
+        float4 a0, b, c;
+        sv_tri(sv, idx, a0, b, c);
         V3 V = mk(b.x, b.y, b.z), W = mk(c.x, c.y, c.z);
         V3 n = mk((V.y * W.z) - (V.z * W.y), (V.z * W.x) - (V.x * W.z), (V.x * W.y) - (V.y * W.x));
         n = normalized(n);
         return normalized(n);
     } else if (kind == 2u) {
-        const float4* bp = reinterpret_cast<const float4*>(P.boxes + idx);
-        float4 a = bp[0], b = bp[1];
+        float4 a, b;
+        sv_box(sv, idx, a, b);
         float t; V3 nn = mk(0.0f, 0.0f, 0.0f);
         hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
         return normalized(nn);
@@ -37,43 +38,54 @@ __device__ __forceinline__ V3 prim_normal(const LaunchParams& P, uint32_t ref, c
 }
 
 struct Mtl { V3 diff; float kd; V3 spec; float ks; float shine, T, ior, refl; };
-__device__ __forceinline__ Mtl load_material(const LaunchParams& P, uint32_t m) {
-    const float4* mp = reinterpret_cast<const float4*>(P.materials + m);
-    float4 a = mp[0], b = mp[1], c = mp[2];
+template <class SV>
+__device__ __forceinline__ Mtl load_material(const SV& sv, uint32_t m) {
+    float4 a, b, c;
+    sv_mat(sv, m, a, b, c);
     Mtl r; r.diff = mk(a.x, a.y, a.z); r.kd = a.w; r.spec = mk(b.x, b.y, b.z); r.ks = b.w;
     r.shine = c.x; r.T = c.y; r.ior = c.z; r.refl = c.w;
     return r;
 }
 
 
-// processLight(), RT/main.cpp:471-526
-template <bool COUNT>
-__device__ __forceinline__ void process_light(const LaunchParams& P, V3 L, V3 lcol, V3& color, const Mtl& M,
-                                              const Ray& ray, V3 precise, V3 normal, TravStack st, Ctr& ctr) {
-    bool insideShadow = false;
-    if (dot(L, normal) > 0.0f) {
-        Ray sr; sr.o = precise; sr.d = L;
-        if (P.accel == 0) {
-            insideShadow = any_hit<COUNT>(P, sr, false, 0.0f, st, ctr);
-        } else {
-            float length = vlen(sr.d);              // BVH::Traverse(Ray&), RT/bvh.cpp:351-352
-            sr.d = normalized(sr.d);
-            insideShadow = any_hit<COUNT>(P, sr, true, length, st, ctr);
-        }
-    }
-    if (!insideShadow) {
-        L = normalized(L);
-        V3 H = normalized(add(L, mul(ray.d, -1.0f)));
-        float VdotN = dot(H, normal);
-        float d1 = dot(normal, L);
-        float max1 = (0.0f < d1) ? d1 : 0.0f;        // std::max(0.0f, x)
-        float max2 = (0.0f < VdotN) ? VdotN : 0.0f;
-        V3 diff = mul(cmul(lcol, M.diff), max1);
-        V3 spec = mul(cmul(lcol, M.spec), powf(max2, M.shine));
-        color = add(color, add(mul(diff, M.kd), mul(mul(spec, M.ks), 0.4f)));
-    }
+// Traversal context of a lane: its private stack (per-lane walk) and its wave's shared stack
+// (packet walk).  PACKET selects the walk at compile time; results are identical.
+struct TravCtx { TravStack lane; WaveStack wave; };
+
+template <bool COUNT, bool PACKET, class SV>
+__device__ __forceinline__ Hit find_closest(const LaunchParams& P, const SV& sv, const Ray& ray, bool active,
+                                            const TravCtx& tc, Ctr& ctr) {
+    if (PACKET) return closest_hit_packet<COUNT>(P, sv, ray, active, tc.wave, ctr);
+    Hit h; h.t = 3.402823466e+38f; h.ref = 0xFFFFFFFFu; h.sid = 0xFFFFFFFFu; h.mat = 0;
+    if (active) h = closest_hit<COUNT>(P, sv, ray, tc.lane, ctr);
+    return h;
 }
 
+// Shadow query of processLight() (RT/main.cpp:476-510).  `need` = this lane builds a shadow
+// ray (L.N > 0).  NONE: un-normalised direction, no distance bound; BVH/GRID: normalised
+// direction and t < |L| (BVH::Traverse(Ray&), RT/bvh.cpp:351-352).
+template <bool COUNT, bool PACKET, class SV>
+__device__ __forceinline__ bool light_occluded(const LaunchParams& P, const SV& sv, V3 L, V3 precise, bool need,
+                                               const TravCtx& tc, Ctr& ctr) {
+    Ray sr; sr.o = precise; sr.d = L;
+    float length = 0.0f;
+    const bool bounded = P.accel != 0;
+    if (bounded) { length = vlen(sr.d); sr.d = normalized(sr.d); }
+    if (PACKET) return any_hit_packet<COUNT>(P, sv, sr, need, bounded, length, tc.wave, ctr);
+    return need ? any_hit<COUNT>(P, sv, sr, bounded, length, tc.lane, ctr) : false;
+}
+// Blinn-Phong term of one unoccluded light, RT/main.cpp:512-525
+__device__ __forceinline__ void light_term(V3 L, V3 lcol, V3& color, const Mtl& M, const Ray& ray, V3 normal) {
+    L = normalized(L);
+    V3 H = normalized(add(L, mul(ray.d, -1.0f)));
+    float VdotN = dot(H, normal);
+    float d1 = dot(normal, L);
+    float max1 = (0.0f < d1) ? d1 : 0.0f;                // std::max(0.0f, x)
+    float max2 = (0.0f < VdotN) ? VdotN : 0.0f;
+    V3 diff = mul(cmul(lcol, M.diff), max1);
+    V3 spec = mul(cmul(lcol, M.spec), powf(max2, M.shine));
+    color = add(color, add(mul(diff, M.kd), mul(mul(spec, M.ks), 0.4f)));
+}
 
 // What one rayTracing() invocation produces before its recursive calls return.
 struct NodeOut {
@@ -94,31 +106,55 @@ __device__ __forceinline__ V3 combine_node(V3 color, float KR, V3 spec, V3 refl_
     return add(color, add(cmul(mul(refl_ret, KR), spec), mul(refr_ret, 1.0f - KR)));
 }
 
-// rayTracing(ray, depth, ior_1) up to (not including) its recursive calls.
-template <bool COUNT>
-__device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const Ray& ray, const Hit& h, int depth,
-                                             float ior_1, TravStack st, Ctr& ctr) {
+// rayTracing(ray, depth, ior_1) up to (not including) its recursive calls.  Written so that
+// the shadow queries sit in wave-uniform control flow (the packet walk needs every lane of the
+// wave to arrive together): lanes without a ray or without a hit carry live == false /
+// hit == false through the light loop instead of leaving early.
+template <bool COUNT, bool PACKET, class SV>
+__device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv, const Ray& ray, const Hit& h,
+                                             bool live, int depth, float ior_1, const TravCtx& tc, Ctr& ctr) {
     NodeOut o;
     o.terminal = true; o.KR = 0.0f; o.mat = h.mat; o.has_refl = false; o.has_refr = false; o.newIor = 1.0f;
     o.color = mk(0.0f, 0.0f, 0.0f);
+    o.ret = o.color;
     o.refl.o = o.color; o.refl.d = o.color; o.refr.o = o.color; o.refr.d = o.color;
-    if (h.ref == 0xFFFFFFFFu) {
+    const bool hit = live && h.ref != 0xFFFFFFFFu;
+    V3 hit_point = o.color, normal = o.color, precise = o.color;
+    if (hit) {                                                           // RT/main.cpp:587-590
+        hit_point = add(ray.o, mul(ray.d, h.t));
+        normal = prim_normal(P, sv, h.ref, ray, hit_point);
+        precise = add(hit_point, mul(normal, P3D_EPS));
+        normal = prim_normal(P, sv, h.ref, ray, precise);
+    }
+    V3 color = mk(0.0f, 0.0f, 0.0f);
+    // lights in groups of 64: first every shadow query of the group (bit i = light i occluded),
+    // then the shading terms in light order -- same sums, same order as the reference's loop
+    for (uint32_t l0 = 0; l0 < P.n_lights; l0 += 64) {
+        const uint32_t ln = (P.n_lights - l0 < 64u) ? (P.n_lights - l0) : 64u;
+        uint64_t occluded = 0;
+        for (uint32_t i = 0; i < ln; i++) {
+            const float4 lpos = reinterpret_cast<const float4*>(P.lights + l0 + i)[0];
+            V3 L = sub(mk(lpos.x, lpos.y, lpos.z), hit_point);
+            const bool need = hit && dot(L, normal) > 0.0f;              // RT/main.cpp:476
+            if (light_occluded<COUNT, PACKET>(P, sv, L, precise, need, tc, ctr)) occluded |= (1ull << i);
+        }
+        if (hit) {
+            Mtl Ml = load_material(sv, h.mat);
+            for (uint32_t i = 0; i < ln; i++) {
+                if (occluded & (1ull << i)) continue;
+                const float4* lp = reinterpret_cast<const float4*>(P.lights + l0 + i);
+                float4 lpos = lp[0], lcol = lp[1];
+                V3 L = sub(mk(lpos.x, lpos.y, lpos.z), hit_point);
+                light_term(L, mk(lcol.x, lcol.y, lcol.z), color, Ml, ray, normal);
+            }
+        }
+    }
+    if (!hit) {
         o.ret = mk(P.bg[0], P.bg[1], P.bg[2]);
         return o;
     }
-    Mtl M = load_material(P, h.mat);
-    V3 hit_point = add(ray.o, mul(ray.d, h.t));
-    V3 normal = prim_normal(P, h.ref, ray, hit_point);
-    V3 precise = add(hit_point, mul(normal, P3D_EPS));
-    normal = prim_normal(P, h.ref, ray, precise);
+    Mtl M = load_material(sv, h.mat);
     V3 Vv = mul(ray.d, -1.0f);
-    V3 color = mk(0.0f, 0.0f, 0.0f);
-    for (uint32_t i = 0; i < P.n_lights; i++) {
-        const float4* lp = reinterpret_cast<const float4*>(P.lights + i);
-        float4 lpos = lp[0], lcol = lp[1];
-        V3 L = sub(mk(lpos.x, lpos.y, lpos.z), hit_point);
-        process_light<COUNT>(P, L, mk(lcol.x, lcol.y, lcol.z), color, M, ray, precise, normal, st, ctr);
-    }
     o.color = color;
     if (depth >= P.max_depth) {                                          // RT/main.cpp:632-634
         o.ret = clampc(color);

@@ -23,6 +23,54 @@ struct Hit {
     uint32_t mat;
 };
 
+// ------------------------------------------------------------------ scene views
+// All per-lane-indexed scene data lives in ONE blob of 16-byte quads (LaunchParams::blob,
+// section offsets in quads).  GlobalScene reads it from HBM/L2/L1 with global_load_dwordx4;
+// LdsScene reads the workgroup's LDS copy (small scenes: ds_read_b128 moves 4x the bytes per
+// clock of the vector L1 return path and same-address lanes broadcast).
+extern __shared__ __attribute__((aligned(16))) uint32_t p3d_lds[];
+
+struct SceneOffsets { uint32_t nodes, refs, spheres, sphere_meta, tris, boxes, mats; };
+
+struct GlobalScene {
+    const float4* q; SceneOffsets o;
+    __device__ __forceinline__ float4 ld4(uint32_t i) const { return q[i]; }
+    __device__ __forceinline__ uint32_t ld1(uint32_t quad, uint32_t dw) const {
+        return reinterpret_cast<const uint32_t*>(q + quad)[dw];
+    }
+    __device__ __forceinline__ uint2 ld2(uint32_t quad, uint32_t pair) const {
+        return reinterpret_cast<const uint2*>(q + quad)[pair];
+    }
+};
+struct LdsScene {
+    SceneOffsets o;
+    __device__ __forceinline__ float4 ld4(uint32_t i) const { return reinterpret_cast<const float4*>(p3d_lds)[i]; }
+    __device__ __forceinline__ uint32_t ld1(uint32_t quad, uint32_t dw) const { return p3d_lds[quad * 4 + dw]; }
+    __device__ __forceinline__ uint2 ld2(uint32_t quad, uint32_t pair) const {
+        return reinterpret_cast<const uint2*>(p3d_lds)[quad * 2 + pair];
+    }
+};
+template <class SV> __device__ __forceinline__ void sv_node(const SV& sv, int32_t n, float4& q0, float4& q1, float4& q2, int4& q3) {
+    uint32_t b = sv.o.nodes + (uint32_t)n * 4u;
+    q0 = sv.ld4(b); q1 = sv.ld4(b + 1); q2 = sv.ld4(b + 2);
+    float4 t = sv.ld4(b + 3);
+    q3 = make_int4(__float_as_int(t.x), __float_as_int(t.y), __float_as_int(t.z), __float_as_int(t.w));
+}
+template <class SV> __device__ __forceinline__ uint32_t sv_leaf_ref(const SV& sv, uint32_t i) { return sv.ld1(sv.o.refs, i); }
+template <class SV> __device__ __forceinline__ float4 sv_sphere(const SV& sv, uint32_t i) { return sv.ld4(sv.o.spheres + i); }
+template <class SV> __device__ __forceinline__ PrimMeta sv_sphere_meta(const SV& sv, uint32_t i) {
+    uint2 m = sv.ld2(sv.o.sphere_meta, i); PrimMeta r; r.scene_id = m.x; r.material = m.y; return r;
+}
+template <class SV> __device__ __forceinline__ void sv_tri(const SV& sv, uint32_t i, float4& a, float4& b, float4& c) {
+    uint32_t q = sv.o.tris + i * 3u; a = sv.ld4(q); b = sv.ld4(q + 1); c = sv.ld4(q + 2);
+}
+template <class SV> __device__ __forceinline__ void sv_box(const SV& sv, uint32_t i, float4& a, float4& b) {
+    uint32_t q = sv.o.boxes + i * 2u; a = sv.ld4(q); b = sv.ld4(q + 1);
+}
+template <class SV> __device__ __forceinline__ void sv_mat(const SV& sv, uint32_t m, float4& a, float4& b, float4& c) {
+    uint32_t q = sv.o.mats + m * 3u; a = sv.ld4(q); b = sv.ld4(q + 1); c = sv.ld4(q + 2);
+}
+
 // LDS traversal stack: 8-byte entries {node ref, entry distance}, [slot][lane]
 struct TravStack {
     uint2* base;         // points at this lane's slot-0 entry; slot stride = 64 entries
@@ -37,7 +85,9 @@ struct SlabRay { float ox, oy, oz, ix, iy, iz; };
 __device__ __forceinline__ SlabRay make_slab(const Ray& r) {
     SlabRay s;
     s.ox = r.o.x; s.oy = r.o.y; s.oz = r.o.z;
-    s.ix = fdiv(1.0f, r.d.x); s.iy = fdiv(1.0f, r.d.y); s.iz = fdiv(1.0f, r.d.z);
+    // 1-ulp hardware reciprocals are enough here: the slab test only has to be conservative
+    // (boxes are padded by >= 1e-3, far above a relative 1e-7), it never decides a hit
+    s.ix = __builtin_amdgcn_rcpf(r.d.x); s.iy = __builtin_amdgcn_rcpf(r.d.y); s.iz = __builtin_amdgcn_rcpf(r.d.z);
     return s;
 }
 // conservative slab test against a padded box; returns entry distance in tn
@@ -53,29 +103,29 @@ __device__ __forceinline__ bool slab(const SlabRay& s, float lx, float ly, float
     return (t0 <= t1) && (t1 >= 0.0f) && (t0 <= tlimit);
 }
 
-template <bool COUNT>
-__device__ __forceinline__ void leaf_closest(const LaunchParams& P, const Ray& r, int32_t leaf,
+template <bool COUNT, class SV>
+__device__ __forceinline__ void leaf_closest(const LaunchParams& P, const SV& sv, const Ray& r, int32_t leaf,
                                              Hit& best, Ctr& ctr) {
     uint32_t code = ~(uint32_t)leaf;
     uint32_t first = code >> 3, n = (code & 7u) + 1u;
     for (uint32_t i = 0; i < n; i++) {
-        uint32_t ref = P.leaf_refs[first + i];
+        uint32_t ref = sv_leaf_ref(sv, first + i);
         uint32_t kind = ref >> kRefKindShift, idx = ref & kRefIndexMask;
         float t; bool h; uint32_t sid = 0, mat = 0;
         if (kind == 1u) {
-            const float4* tp = reinterpret_cast<const float4*>(P.tris + idx);
-            float4 a = tp[0], b = tp[1], c = tp[2];
+            float4 a, b, c;
+            sv_tri(sv, idx, a, b, c);
             if (COUNT) ctr.tri++;
             h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
             sid = __float_as_uint(a.w); mat = __float_as_uint(b.w);
         } else if (kind == 0u) {
-            float4 s = *reinterpret_cast<const float4*>(P.spheres + idx);
+            float4 s = sv_sphere(sv, idx);
             if (COUNT) ctr.sph++;
             h = hit_sphere(r, mk(s.x, s.y, s.z), s.w, t);
-            if (h && t <= best.t) { PrimMeta m = P.sphere_meta[idx]; sid = m.scene_id; mat = m.material; }
+            if (h && t <= best.t) { PrimMeta m = sv_sphere_meta(sv, idx); sid = m.scene_id; mat = m.material; }
         } else {
-            const float4* bp = reinterpret_cast<const float4*>(P.boxes + idx);
-            float4 a = bp[0], b = bp[1];
+            float4 a, b;
+            sv_box(sv, idx, a, b);
             V3 nn;
             if (COUNT) ctr.aab++;
             h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
@@ -89,8 +139,8 @@ __device__ __forceinline__ void leaf_closest(const LaunchParams& P, const Ray& r
 }
 
 // closest hit over planes (unbounded, outside the BVH) + BVH
-template <bool COUNT>
-__device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const Ray& r, TravStack st, Ctr& ctr) {
+template <bool COUNT, class SV>
+__device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const SV& sv, const Ray& r, TravStack st, Ctr& ctr) {
     Hit best; best.t = 3.402823466e+38f; best.ref = 0xFFFFFFFFu; best.sid = 0xFFFFFFFFu; best.mat = 0;
     if (COUNT) ctr.closest++;
     for (uint32_t i = 0; i < P.n_planes; i++) {
@@ -109,9 +159,8 @@ __device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const Ray& r, 
     int32_t cur = 0;
     while (cur != P3D_DONE) {
         while (cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(P.nodes + cur);
-            float4 q0 = np[0], q1 = np[1], q2 = np[2];
-            int4 q3 = *reinterpret_cast<const int4*>(np + 3);
+            float4 q0, q1, q2; int4 q3;
+            sv_node(sv, cur, q0, q1, q2, q3);
             float tn0, tn1;
             bool h0 = slab(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best.t, tn0);
             bool h1 = slab(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best.t, tn1);
@@ -134,7 +183,7 @@ __device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const Ray& r, 
             }
         }
         if (cur != P3D_DONE) {
-            leaf_closest<COUNT>(P, r, cur, best, ctr);
+            leaf_closest<COUNT>(P, sv, r, cur, best, ctr);
             cur = P3D_DONE;
             while (sp > 0) {
                 sp--;
@@ -148,28 +197,28 @@ __device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const Ray& r, 
 
 // any hit with t < tmax (tmax = +inf, bounded == false: "any intercepts() at all", the
 // NONE-mode shadow loop of RT/main.cpp:480-487)
-template <bool COUNT>
-__device__ __forceinline__ bool leaf_any(const LaunchParams& P, const Ray& r, int32_t leaf, bool bounded,
+template <bool COUNT, class SV>
+__device__ __forceinline__ bool leaf_any(const LaunchParams& P, const SV& sv, const Ray& r, int32_t leaf, bool bounded,
                                          float tmax, Ctr& ctr) {
     uint32_t code = ~(uint32_t)leaf;
     uint32_t first = code >> 3, n = (code & 7u) + 1u;
     bool occluded = false;
     for (uint32_t i = 0; i < n; i++) {
-        uint32_t ref = P.leaf_refs[first + i];
+        uint32_t ref = sv_leaf_ref(sv, first + i);
         uint32_t kind = ref >> kRefKindShift, idx = ref & kRefIndexMask;
         float t; bool h;
         if (kind == 1u) {
-            const float4* tp = reinterpret_cast<const float4*>(P.tris + idx);
-            float4 a = tp[0], b = tp[1], c = tp[2];
+            float4 a, b, c;
+            sv_tri(sv, idx, a, b, c);
             if (COUNT) ctr.tri++;
             h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
         } else if (kind == 0u) {
-            float4 s = *reinterpret_cast<const float4*>(P.spheres + idx);
+            float4 s = sv_sphere(sv, idx);
             if (COUNT) ctr.sph++;
             h = hit_sphere(r, mk(s.x, s.y, s.z), s.w, t);
         } else {
-            const float4* bp = reinterpret_cast<const float4*>(P.boxes + idx);
-            float4 a = bp[0], b = bp[1];
+            float4 a, b;
+            sv_box(sv, idx, a, b);
             V3 nn;
             if (COUNT) ctr.aab++;
             h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
@@ -179,8 +228,8 @@ __device__ __forceinline__ bool leaf_any(const LaunchParams& P, const Ray& r, in
     return occluded;
 }
 
-template <bool COUNT>
-__device__ __forceinline__ bool any_hit(const LaunchParams& P, const Ray& r, bool bounded, float tmax,
+template <bool COUNT, class SV>
+__device__ __forceinline__ bool any_hit(const LaunchParams& P, const SV& sv, const Ray& r, bool bounded, float tmax,
                                         TravStack st, Ctr& ctr) {
     if (COUNT) ctr.shadow++;
     if (P.n_planes) {
@@ -202,9 +251,8 @@ __device__ __forceinline__ bool any_hit(const LaunchParams& P, const Ray& r, boo
     int32_t cur = 0;
     while (cur != P3D_DONE) {
         while (cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(P.nodes + cur);
-            float4 q0 = np[0], q1 = np[1], q2 = np[2];
-            int4 q3 = *reinterpret_cast<const int4*>(np + 3);
+            float4 q0, q1, q2; int4 q3;
+            sv_node(sv, cur, q0, q1, q2, q3);
             float tn0, tn1;
             bool h0 = slab(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tlimit, tn0);
             bool h1 = slab(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tlimit, tn1);
@@ -219,7 +267,7 @@ __device__ __forceinline__ bool any_hit(const LaunchParams& P, const Ray& r, boo
             else cur = P3D_DONE;
         }
         if (cur != P3D_DONE) {
-            if (leaf_any<COUNT>(P, r, cur, bounded, tmax, ctr)) return true;
+            if (leaf_any<COUNT>(P, sv, r, cur, bounded, tmax, ctr)) return true;
             if (sp > 0) { sp--; cur = (int32_t)st.at(sp).x; }
             else cur = P3D_DONE;
         }
@@ -227,6 +275,191 @@ __device__ __forceinline__ bool any_hit(const LaunchParams& P, const Ray& r, boo
     return false;
 }
 
+
+// ------------------------------------------------------------------ wave-wide (packet) traversal
+// For small trees the 64 rays of a wave walk the BVH TOGETHER: the node index is wave-uniform,
+// so node and primitive records are fetched once per wave (broadcast LDS reads or scalar
+// loads), the traversal stack is one LDS dword per entry for the whole wave, primitive-kind
+// dispatch is a scalar branch, and lanes only differ in their exec bit.  A node is visited when
+// ANY lane's slab test passes (ballot).  Incoherent rays make the wave visit the union of the
+// lanes' paths, which for a tree of a few nodes is still far cheaper than 64 private walks
+// with divergent loops; large scenes use the per-lane walk above.  Results are identical:
+// the hit rule (nearest t, lowest scene index on ties) does not depend on visit order.
+// Both functions must be called by all lanes of the wave together (converged), with
+// `active` = this lane has a ray.
+struct WaveStack {
+    int32_t* base;       // this WAVE's region (same address in every lane)
+    __device__ __forceinline__ void push(int sp, int32_t node) { base[sp] = node; }
+    __device__ __forceinline__ int32_t at(int sp) const { return __builtin_amdgcn_readfirstlane(base[sp]); }
+};
+
+template <bool COUNT, class SV>
+__device__ __forceinline__ void leaf_closest_packet(const LaunchParams& P, const SV& sv, const Ray& r, bool live,
+                                                    int32_t leaf, Hit& best, Ctr& ctr) {
+    const uint32_t code = ~(uint32_t)leaf;
+    const uint32_t first = code >> 3, n = (code & 7u) + 1u;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t ref = __builtin_amdgcn_readfirstlane(sv_leaf_ref(sv, first + i));
+        const uint32_t kind = ref >> kRefKindShift, idx = ref & kRefIndexMask;
+        if (kind == 1u) {
+            float4 a, b, c;
+            sv_tri(sv, idx, a, b, c);
+            if (live) {
+                float t;
+                if (COUNT) ctr.tri++;
+                bool h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
+                uint32_t sid = __float_as_uint(a.w);
+                if (h && (t < best.t || (t == best.t && sid < best.sid))) {
+                    best.t = t; best.ref = ref; best.sid = sid; best.mat = __float_as_uint(b.w);
+                }
+            }
+        } else if (kind == 0u) {
+            float4 s = sv_sphere(sv, idx);
+            PrimMeta m = sv_sphere_meta(sv, idx);
+            if (live) {
+                float t;
+                if (COUNT) ctr.sph++;
+                bool h = hit_sphere(r, mk(s.x, s.y, s.z), s.w, t);
+                if (h && (t < best.t || (t == best.t && m.scene_id < best.sid))) {
+                    best.t = t; best.ref = ref; best.sid = m.scene_id; best.mat = m.material;
+                }
+            }
+        } else {
+            float4 a, b;
+            sv_box(sv, idx, a, b);
+            if (live) {
+                float t; V3 nn;
+                if (COUNT) ctr.aab++;
+                bool h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
+                uint32_t sid = __float_as_uint(a.w);
+                if (h && (t < best.t || (t == best.t && sid < best.sid))) {
+                    best.t = t; best.ref = ref; best.sid = sid; best.mat = __float_as_uint(b.w);
+                }
+            }
+        }
+    }
+}
+
+template <bool COUNT, class SV>
+__device__ __forceinline__ Hit closest_hit_packet(const LaunchParams& P, const SV& sv, const Ray& r, bool active,
+                                                  WaveStack ws, Ctr& ctr) {
+    Hit best; best.t = 3.402823466e+38f; best.ref = 0xFFFFFFFFu; best.sid = 0xFFFFFFFFu; best.mat = 0;
+    if (COUNT && active) ctr.closest++;
+    for (uint32_t i = 0; i < P.n_planes; i++) {
+        PlaneRec pl = P.planes[i];
+        PrimMeta m = P.plane_meta[i];
+        float t;
+        if (active) {
+            if (COUNT) ctr.pln++;
+            if (hit_plane(r, mk(pl.nx, pl.ny, pl.nz), pl.d, t) &&
+                (t < best.t || (t == best.t && m.scene_id < best.sid))) {
+                best.t = t; best.ref = (3u << kRefKindShift) | i; best.sid = m.scene_id; best.mat = m.material;
+            }
+        }
+    }
+    if (__ballot(active) == 0) return best;
+    SlabRay s = make_slab(r);
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        float4 q0, q1, q2; int4 q3;
+        sv_node(sv, cur, q0, q1, q2, q3);
+        float tn0 = 0.0f, tn1 = 0.0f;
+        const bool h0 = active && slab(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best.t, tn0);
+        const bool h1 = active && slab(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best.t, tn1);
+        if (COUNT && active) ctr.box += 2;
+        uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+        const int32_t c0 = __builtin_amdgcn_readfirstlane(q3.x), c1 = __builtin_amdgcn_readfirstlane(q3.y);
+        if (m0 && c0 < 0) { leaf_closest_packet<COUNT>(P, sv, r, h0, c0, best, ctr); m0 = 0; }
+        if (m1 && c1 < 0) { leaf_closest_packet<COUNT>(P, sv, r, h1, c1, best, ctr); m1 = 0; }
+        if (m0 && m1) {
+            // near child first as seen by the first lane that wants both (any order is correct)
+            const uint64_t both = m0 & m1;
+            const int f = both ? (int)__builtin_ctzll(both) : (int)__builtin_ctzll(m0);
+            const bool swap = __shfl(tn1, f) < __shfl(tn0, f);
+            ws.push(sp, swap ? c0 : c1); sp++;
+            cur = swap ? c1 : c0;
+        } else if (m0) cur = c0;
+        else if (m1) cur = c1;
+        else {
+            if (sp == 0) break;
+            sp--; cur = ws.at(sp);
+        }
+    }
+    return best;
+}
+
+// per-lane result: occluded (any primitive hit, with t < tmax when bounded)
+template <bool COUNT, class SV>
+__device__ __forceinline__ bool any_hit_packet(const LaunchParams& P, const SV& sv, const Ray& r, bool active,
+                                               bool bounded, float tmax, WaveStack ws, Ctr& ctr) {
+    bool occ = false;
+    if (COUNT && active) ctr.shadow++;
+    if (P.n_planes) {
+        const bool gate = active && (!bounded || ref_unit_box_hit(r));
+        for (uint32_t i = 0; i < P.n_planes; i++) {
+            PlaneRec pl = P.planes[i];
+            float t;
+            if (gate && !occ) {
+                if (COUNT) ctr.pln++;
+                if (hit_plane(r, mk(pl.nx, pl.ny, pl.nz), pl.d, t) && (!bounded || t < tmax)) occ = true;
+            }
+        }
+    }
+    if (__ballot(active && !occ) == 0) return occ;
+    SlabRay s = make_slab(r);
+    const float tlimit = bounded ? tmax : 3.402823466e+38f;
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        float4 q0, q1, q2; int4 q3;
+        sv_node(sv, cur, q0, q1, q2, q3);
+        float tn0, tn1;
+        const bool live = active && !occ;
+        const bool h0 = live && slab(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tlimit, tn0);
+        const bool h1 = live && slab(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tlimit, tn1);
+        if (COUNT && live) ctr.box += 2;
+        uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+        const int32_t c0 = __builtin_amdgcn_readfirstlane(q3.x), c1 = __builtin_amdgcn_readfirstlane(q3.y);
+        for (int side = 0; side < 2; side++) {
+            const int32_t c = side ? c1 : c0;
+            const uint64_t m = side ? m1 : m0;
+            if (!(m && c < 0)) continue;
+            const bool hl = (side ? h1 : h0) && !occ;
+            const uint32_t code = ~(uint32_t)c;
+            const uint32_t first = code >> 3, n = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t ref = __builtin_amdgcn_readfirstlane(sv_leaf_ref(sv, first + i));
+                const uint32_t kind = ref >> kRefKindShift, idx = ref & kRefIndexMask;
+                float t; bool h = false;
+                if (kind == 1u) {
+                    float4 a, b, cc;
+                    sv_tri(sv, idx, a, b, cc);
+                    if (hl && !occ) { if (COUNT) ctr.tri++; h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(cc.x, cc.y, cc.z), t); }
+                } else if (kind == 0u) {
+                    float4 sp4 = sv_sphere(sv, idx);
+                    if (hl && !occ) { if (COUNT) ctr.sph++; h = hit_sphere(r, mk(sp4.x, sp4.y, sp4.z), sp4.w, t); }
+                } else {
+                    float4 a, b; V3 nn;
+                    sv_box(sv, idx, a, b);
+                    if (hl && !occ) { if (COUNT) ctr.aab++; h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn); }
+                }
+                if (h && (!bounded || t < tmax)) occ = true;
+            }
+        }
+        if (m0 && c0 < 0) m0 = 0;
+        if (m1 && c1 < 0) m1 = 0;
+        if (__ballot(active && !occ) == 0) break;
+        if (m0 && m1) { ws.push(sp, c1); sp++; cur = c0; }
+        else if (m0) cur = c0;
+        else if (m1) cur = c1;
+        else {
+            if (sp == 0) break;
+            sp--; cur = ws.at(sp);
+        }
+    }
+    return occ;
+}
 
 }  // namespace p3d
 #endif
