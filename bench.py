@@ -12,9 +12,14 @@ gather of the compact tile buffers to rank 0 plus the de-interleave kernel there
 value = rays of all frames / max-over-ranks wall time; a ray is one closest-hit or one shadow
 query, counted by the counting build of the same kernel on the same frame.
 
-Extra objects on the JSON line: "roofline" (algorithmic bytes of the frame kernel / its mean
-duration from HIP events on the launch stream, vs the 8 TB/s HBM peak) and, at N=1,
-"cpu_baseline" (the CPU oracle timed on this box's host cores).
+A frame is the wavefront schedule: wf_primary_kernel (camera rays + their shadow rays +
+shading), one wf_secondary_kernel per deeper tree level, and the resolve passes.
+
+Extra objects on the JSON line: "roofline" for the dominant kernel wf_primary_kernel
+(algorithmic bytes of ITS launch -- counted by the counting build run at depth 1, which is
+exactly the level-1 work -- divided by its mean duration from HIP events on the launch
+stream, vs the 8 TB/s HBM peak; traffic = PMC-measured HBM bytes per launch from
+profiles/) and, at N=1, "cpu_baseline" (the CPU oracle timed on this box's host cores).
 """
 import argparse
 import json
@@ -146,13 +151,23 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    # kernel-only pass for the roofline: HIP events on the launch stream around K*B frame launches
+    # roofline pass: HIP events on the launch stream around each frame and around its dominant
+    # kernel (wf_primary_kernel), averaged over steps*B frames
     nl = max(args.steps, 1) * B
-    ds.timer_begin()
+    frame_ms_sum = kern_ms_sum = 0.0
     for _ in range(nl):
         ds.render_device(cam, rgb8_ptr=tiles[0].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
-                         rank=rank, world=world, row_block=ROW_BLOCK)
-    kern_ms = ds.timer_end() / nl
+                         rank=rank, world=world, row_block=ROW_BLOCK, profile=True)
+        f_ms, k_ms = ds.profile()
+        frame_ms_sum += f_ms
+        kern_ms_sum += k_ms
+    kern_ms = kern_ms_sum / nl
+    frame_dev_ms = frame_ms_sum / nl
+    # level-1 work of this rank's rows = a depth-1 frame (primary closest hits + their shadow queries)
+    ds.render_device(cam, rgb8_ptr=tiles[0].data_ptr(), max_depth=1, accel=P.ACCEL_BVH,
+                     rank=rank, world=world, row_block=ROW_BLOCK, counters=True)
+    c1 = ds.counters()
+    alg_bytes_l1 = c1["algorithmic_bytes"] + 3 * c1["pixels"]
 
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     rr = torch.tensor([float(my_rays)], dtype=torch.float64, device=dev)
@@ -166,7 +181,13 @@ def main():
         # the frame that was timed is the frame the parity tests check: verify against the oracle's golden
         final = (frames[B - 1] if world > 1 else tiles[B - 1][:H]).cpu().numpy()
         total_rays = rays_frame * B * args.steps
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        achieved = alg_bytes_l1 / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(REPO, "profiles", "r01_v4_pmc_traffic.json")))
+            traffic = prof["kernels"]["wf_primary_kernel<false, true, false, 1>"]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            pass
         line = {
             "metric": "Mrays/s + ms/frame @1920x1080 depth4",
             "value": total_rays / dt_max / 1e6,
@@ -184,12 +205,16 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved 16-row blocks + RCCL gather to rank 0" % world,
                        "frame_checksum": int(final.astype(np.uint64).sum())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "whitted_frame_kernel<false>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "wf_primary_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": int(alg_bytes_l1),
+                         "frame_device_ms": frame_dev_ms,
+                         "frame_algorithmic_bytes": int(alg_bytes),
+                         "frame_algorithmic_GBps": alg_bytes / (frame_dev_ms * 1e-3) / 1e9,
                          "note": "algorithmic bytes = 32 B/slab test + 16/48/32 B per sphere/triangle/box test + 3 B/px "
-                                 "(SURVEY 8d); the 12-primitive scene is LDS/L1-resident, real HBM traffic is the "
-                                 "frame buffer only (see DESIGN.md)"},
+                                 "(SURVEY 8d). The 12-primitive scene is LDS-resident: `traffic` (PMC FETCH_SIZE x2 + "
+                                 "WRITE_SIZE per launch, profiles/r01_v4_pmc_traffic.json, 1-GPU whole-frame launch) is "
+                                 "frame buffer + ray/node queues, far below the algorithmic figure (see DESIGN.md)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene_file)

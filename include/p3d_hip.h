@@ -101,6 +101,8 @@ typedef struct p3d_render_params {
 } p3d_render_params;
 
 #define P3D_FLAG_COUNTERS 1u     /* accumulate p3d_counters on the device (slower kernels)  */
+#define P3D_FLAG_PROFILE 16u     /* bracket the frame and its dominant kernel (the level-1 /
+                                    tree launch) with HIP events for p3d_get_profile()           */
 #define P3D_FLAG_NO_PACKET 8u    /* per-lane BVH walk even for trees small enough for the
                                     wave-wide (packet) walk                                       */
 #define P3D_FLAG_NO_LDS_SCENE 4u /* read the scene from HBM/L2 even when it would fit in LDS    */
@@ -175,6 +177,12 @@ int p3d_get_counters(p3d_scene* scene, p3d_counters* out);
  * waves_per_simd = register budget of the ray kernels expressed as resident waves per SIMD:
  * 0 compiler default, 5 / 6 trade spilled registers for latency hiding, -1 keeps. */
 int p3d_set_tuning(p3d_scene* scene, int32_t xcd_chunk, int32_t workspace_mib, int32_t waves_per_simd);
+
+/* Elapsed device time of the most recent render made with P3D_FLAG_PROFILE (waits for it):
+ * the whole frame (all launches of the call, samples and bands included) and its dominant
+ * kernel alone -- wf_primary_kernel, or whitted_tree_kernel with P3D_FLAG_TREE_KERNEL -- for
+ * the first sample / band. HIP events on the scene's stream. */
+int p3d_get_profile(p3d_scene* scene, float* frame_ms, float* kernel_ms);
 
 /* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the
  * scene's own stream. */

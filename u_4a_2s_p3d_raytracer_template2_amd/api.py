@@ -14,6 +14,7 @@ FLAG_COUNTERS = 1
 FLAG_TREE_KERNEL = 2
 FLAG_NO_LDS_SCENE = 4
 FLAG_NO_PACKET = 8
+FLAG_PROFILE = 16
 
 
 class P3DError(RuntimeError):
@@ -74,7 +75,7 @@ class SceneStats(C.Structure):
 # every symbol include/p3d_hip.h declares (tests check that the library exports them all)
 C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_scene_create",
                  "p3d_scene_destroy", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
-                 "p3d_get_counters", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end",
+                 "p3d_get_counters", "p3d_get_profile", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end",
                  "p3d_deinterleave", "p3d_debug_intersect"]
 
 
@@ -117,6 +118,7 @@ def lib():
     L.p3d_sync.argtypes = [C.c_void_p]
     L.p3d_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.p3d_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.p3d_get_profile.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.p3d_set_tuning.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.p3d_timer_begin.argtypes = [C.c_void_p]
     L.p3d_timer_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -295,21 +297,27 @@ class DeviceScene:
         _check(lib().p3d_timer_end(self.h, C.byref(ms)), "p3d_timer_end")
         return ms.value
 
+    def profile(self):
+        """(frame_ms, dominant_kernel_ms) of the last render made with profile=True."""
+        f, k = C.c_float(0), C.c_float(0)
+        _check(lib().p3d_get_profile(self.h, C.byref(f), C.byref(k)), "p3d_get_profile")
+        return f.value, k.value
+
     def counters(self):
         c = Counters()
         _check(lib().p3d_get_counters(self.h, C.byref(c)), "p3d_get_counters")
         return c.as_dict()
 
-    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, no_packet=False):
+    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, no_packet=False, profile=False):
         p = RenderParams()
         p.max_depth, p.accel, p.spp = int(max_depth), int(accel), int(spp)
         p.samples = samples.ctypes.data_as(C.POINTER(C.c_float)) if samples is not None else None
         p.row_block, p.rank, p.world = int(row_block), int(rank), int(world)
-        p.flags = (FLAG_COUNTERS if counters else 0) | (FLAG_TREE_KERNEL if tree else 0) | (FLAG_NO_LDS_SCENE if no_lds else 0) | (FLAG_NO_PACKET if no_packet else 0)
+        p.flags = (FLAG_COUNTERS if counters else 0) | (FLAG_TREE_KERNEL if tree else 0) | (FLAG_NO_LDS_SCENE if no_lds else 0) | (FLAG_NO_PACKET if no_packet else 0) | (FLAG_PROFILE if profile else 0)
         return p
 
     def render(self, cam, max_depth=4, accel=ACCEL_BVH, spp=0, samples=None, rank=0, world=1, row_block=16,
-               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, no_packet=False):
+               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, no_packet=False, profile=False):
         """Render into host numpy arrays (rows: res_y for world==1, local_rows otherwise)."""
         rows = cam.res_y if world == 1 else local_rows(cam.res_y, row_block, world)
         rgb8 = np.zeros((rows, cam.res_x, 3), np.uint8)
@@ -317,7 +325,7 @@ class DeviceScene:
         hid = np.full((rows, cam.res_x), -2, np.int32) if want_hit else None
         if samples is not None:
             samples = np.ascontiguousarray(samples, np.float32)
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile)
         o = Outputs(rgb8.ctypes.data, f32.ctypes.data if want_f32 else None,
                     hid.ctypes.data if want_hit else None, 0)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
@@ -327,9 +335,9 @@ class DeviceScene:
         return out
 
     def render_device(self, cam, rgb8_ptr=0, rgb32f_ptr=0, hit_ptr=0, max_depth=4, accel=ACCEL_BVH, spp=0,
-                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, no_packet=False):
+                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, no_packet=False, profile=False):
         """Enqueue one frame into caller-owned DEVICE buffers (raw pointers); asynchronous."""
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile)
         o = Outputs(rgb8_ptr or None, rgb32f_ptr or None, hit_ptr or None, 1)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
 

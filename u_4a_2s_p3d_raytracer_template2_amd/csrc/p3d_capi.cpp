@@ -103,6 +103,8 @@ struct p3d_scene {
     DeviceCounters* d_counters = nullptr;
     bool counters_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_prof[4] = {nullptr, nullptr, nullptr, nullptr};   // frame begin/end, dominant kernel begin/end
+    bool profile_valid = false;
     bool timer_open = false;
     size_t lds_prepared = 0;
     int xcd_chunk = 1;
@@ -165,6 +167,7 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     s->stream = s->own_stream;
     if ((e = hipEventCreate(&s->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&s->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    for (auto& ev : s->ev_prof) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
     {   // pack the per-lane-indexed arrays into one blob of 16-byte quads
         std::vector<uint32_t> blob;
         auto section = [&](const void* data, size_t bytes) {
@@ -214,6 +217,7 @@ int p3d_scene_destroy(p3d_scene* s) {
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (auto& ev : s->ev_prof) if (ev) (void)hipEventDestroy(ev);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
     return P3D_OK;
@@ -260,7 +264,7 @@ constexpr int kShards = 64;   // queue shards (power of two); spreads the slot-a
 // One sample pass over one band of tile rows, level by level (see p3d_kernels.hip).
 // shard_px = pixels a shard can own in this band (worst case), so level l holds at most
 // shard_px << (l-1) rays / nodes per shard.
-int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, bool lds, bool packet, size_t shard_px) {
+int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, bool lds, bool packet, size_t shard_px, bool profile) {
     const int D = P.max_depth;
     uint32_t* counts = (uint32_t*)s->wf_counts.p;      // [level][shard] ray counts, then node counts
     const size_t n_counts = (size_t)2 * (kMaxDepth + 2) * kShards;
@@ -276,7 +280,9 @@ int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, bool lds, bool 
     P.wf_rays_out = rays(2); P.wf_count_out = qcount(2); P.wf_cap_out = cap(2);
     P.wf_nodes_parent = nullptr; P.wf_ncap_parent = 0;
     P.wf_nodes_self = nodes(1); P.wf_ncount_self = ncount(1); P.wf_ncap_self = cap(1);
+    if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
     HIP_TRY(launch_wf_primary(P, count, lds, packet, s->occupancy, s->stream));
+    if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream));
     for (int l = 2; l <= D; l++) {
         P.wf_level = l;
         P.wf_rays_in = rays(l); P.wf_count_in = qcount(l); P.wf_cap_in = cap(l);
@@ -379,9 +385,13 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         s->counters_valid = true;
     }
     P.wf_nsamples = prm->spp > 0 ? prm->spp * prm->spp : 1;
+    const bool profile = (prm->flags & P3D_FLAG_PROFILE) != 0;
+    if (profile) HIP_TRY(hipEventRecord(s->ev_prof[0], s->stream));
     if (use_tree) {
         P.wf_tile_row0 = 0; P.wf_tile_rows = P.tiles_y;
+        if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
         HIP_TRY(launch_tree(P, count, lds_scene, s->occupancy, s->stream));
+        if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream));
     } else {
         const int D = prm->max_depth;
         // a shard owns every kShards-th tile of the band
@@ -401,11 +411,12 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
                 B.n_tiles = B.tiles_x * B.wf_tile_rows;
                 int chunks = (B.n_tiles + B.xcd_chunk - 1) / B.xcd_chunk;
                 B.grid_blocks = ((chunks + 7) / 8) * 8 * B.xcd_chunk;
-                int rc = run_wavefront_pass(s, B, count, lds_scene, packet, shard_px);
+                int rc = run_wavefront_pass(s, B, count, lds_scene, packet, shard_px, profile && smp == 0 && r0 == 0);
                 if (rc) return rc;
             }
         }
     }
+    if (profile) { HIP_TRY(hipEventRecord(s->ev_prof[1], s->stream)); s->profile_valid = true; }
     if (out->memory != 1) {
         // host planes hold res_y rows for a whole frame, p3d_local_rows() rows for a shard
         const size_t cpx = (world == 1 ? (size_t)cam->res_y : (size_t)P.local_rows) * cam->res_x;
@@ -434,6 +445,16 @@ int p3d_get_counters(p3d_scene* s, p3d_counters* out) {
     out->closest_queries = c.closest_queries; out->shadow_queries = c.shadow_queries;
     out->box_tests = c.box_tests; out->sphere_tests = c.sphere_tests; out->tri_tests = c.tri_tests;
     out->aabox_tests = c.aabox_tests; out->plane_tests = c.plane_tests; out->pixels = c.pixels;
+    return P3D_OK;
+}
+
+int p3d_get_profile(p3d_scene* s, float* frame_ms, float* kernel_ms) {
+    if (!s || !frame_ms || !kernel_ms) return fail(P3D_ERR_ARG, "NULL argument");
+    if (!s->profile_valid) return fail(P3D_ERR_STATE, "no render with P3D_FLAG_PROFILE yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev_prof[1]));
+    HIP_TRY(hipEventElapsedTime(frame_ms, s->ev_prof[0], s->ev_prof[1]));
+    HIP_TRY(hipEventElapsedTime(kernel_ms, s->ev_prof[2], s->ev_prof[3]));
     return P3D_OK;
 }
 
