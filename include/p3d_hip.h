@@ -201,6 +201,12 @@ int p3d_deinterleave(p3d_scene* scene, const void* gathered, void* frame, int32_
                      int32_t res_y, int32_t row_block, int32_t world, int32_t bytes_per_pixel,
                      uint64_t rank_stride_bytes);
 
+/* Diagnostic: with a device buffer of (tiles x waves-per-workgroup x 8) uint64 set here, the
+ * level-1 kernel writes per-wave 100 MHz timestamps (tile start, after ray generation, after the
+ * closest hit, after shading, after the queue append; slot 7 = hardware id). NULL turns it off
+ * (default). Never changes results. tools/stamps.py turns them into a per-stage timeline. */
+int p3d_debug_set_stamps(p3d_scene* scene, void* device_buffer);
+
 /* Unit-level probe used by the parity tests: intersect n rays with one primitive each using
  * the DEVICE intersectors (Sphere/Triangle/aaBox/Plane::intercepts, RT/scene.cpp:55-283).
  * Host arrays: type[n], prim12[n*12] (plane = PN,D), origin[n*3], dir[n*3] -> hit[n], t[n],

@@ -76,7 +76,7 @@ class SceneStats(C.Structure):
 C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_scene_create",
                  "p3d_scene_destroy", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
                  "p3d_get_counters", "p3d_get_profile", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end",
-                 "p3d_deinterleave", "p3d_debug_intersect"]
+                 "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_set_stamps"]
 
 
 def build_native(verbose=False):
@@ -124,6 +124,7 @@ def lib():
     L.p3d_timer_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.p3d_deinterleave.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_uint64]
+    L.p3d_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
     L.p3d_debug_intersect.argtypes = [C.c_int, C.c_uint32] + [C.c_void_p] * 7
     # host shim
     L.p3dh_scene_load.restype = C.c_void_p
@@ -302,6 +303,9 @@ class DeviceScene:
         f, k = C.c_float(0), C.c_float(0)
         _check(lib().p3d_get_profile(self.h, C.byref(f), C.byref(k)), "p3d_get_profile")
         return f.value, k.value
+
+    def debug_set_stamps(self, ptr):
+        _check(lib().p3d_debug_set_stamps(self.h, C.c_void_p(ptr or None)), "p3d_debug_set_stamps")
 
     def counters(self):
         c = Counters()

@@ -24,6 +24,7 @@ hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, bool p
 hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, bool packet, int occ, unsigned waves,
                                hipStream_t stream);
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream);
+hipError_t launch_raygen_table(float* fx, float* fy, int res_x, int res_y, hipStream_t stream);
 hipError_t prepare_kernels(size_t max_lds);
 hipError_t launch_deinterleave(const void* gathered, void* frame, int res_x, int res_y, int row_block,
                                int world, size_t rank_stride, int bpp, hipStream_t stream);
@@ -97,6 +98,7 @@ struct p3d_scene {
     uint32_t n_lights = 0, n_materials = 0;
     p3d_scene_stats stats{};
     RawBuf fb_rgb8, fb_rgb32f, fb_hit, samples;
+    RawBuf ray_tab; int tab_res_x = 0, tab_res_y = 0;   // cached per-column / per-row ray factors
     // wavefront workspace: ray queues (levels 2..D), parked nodes (levels 1..D-1), counters
     RawBuf wf_rays[kMaxDepth + 2], wf_nodes[kMaxDepth + 2], wf_counts, wf_accum;
     size_t workspace_budget = (size_t)8 << 30;
@@ -108,6 +110,7 @@ struct p3d_scene {
     bool timer_open = false;
     size_t lds_prepared = 0;
     int xcd_chunk = 1;
+    unsigned long long* dbg_stamps = nullptr;
     int occupancy = 0;     // 0 = compiler default register budget, else 5 / 6 / 8 waves per SIMD
 };
 
@@ -210,7 +213,7 @@ int p3d_scene_destroy(p3d_scene* s) {
     (void)hipSetDevice(s->device);
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     s->blob.release(); s->planes.release(); s->plane_meta.release(); s->lights.release();
-    s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release();
+    s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release(); s->ray_tab.release();
     for (auto& b : s->wf_rays) b.release();
     for (auto& b : s->wf_nodes) b.release();
     s->wf_counts.release(); s->wf_accum.release();
@@ -337,6 +340,15 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     memcpy(P.v, cam->v, sizeof P.v); memcpy(P.n, cam->n, sizeof P.n);
     P.w = cam->w; P.h = cam->h; P.plane_dist = cam->plane_dist; P.aperture = cam->aperture;
     P.focal_ratio = cam->focal_ratio; P.res_x = cam->res_x; P.res_y = cam->res_y;
+    for (int a = 0; a < 3; a++) {               // same float products Camera::PrimaryRay forms per call
+        P.uw[a] = cam->u[a] * cam->w; P.vh[a] = cam->v[a] * cam->h; P.vz[a] = cam->n[a] * -cam->plane_dist;
+    }
+    if (s->tab_res_x != cam->res_x || s->tab_res_y != cam->res_y) {
+        HIP_TRY(s->ray_tab.ensure(((size_t)cam->res_x + cam->res_y) * sizeof(float)));
+        HIP_TRY(launch_raygen_table((float*)s->ray_tab.p, (float*)s->ray_tab.p + cam->res_x, cam->res_x, cam->res_y, s->stream));
+        s->tab_res_x = cam->res_x; s->tab_res_y = cam->res_y;
+    }
+    P.ray_fx = (const float*)s->ray_tab.p; P.ray_fy = P.ray_fx + cam->res_x;
     P.max_depth = prm->max_depth; P.accel = prm->accel; P.spp = prm->spp;
     P.row_block = row_block; P.rank = rank; P.world = world;
     P.local_rows = p3d_local_rows(cam->res_y, row_block, world);
@@ -349,6 +361,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         P.grid_blocks = ((chunks + 7) / 8) * 8 * P.xcd_chunk;
     }
     P.counters = s->d_counters;
+    P.dbg_stamps = s->dbg_stamps;
 
     const bool tree_requested = (prm->flags & P3D_FLAG_TREE_KERNEL) != 0;
     // wavefront bands: worst-case queues for a band of tile rows must fit the workspace budget
@@ -445,6 +458,12 @@ int p3d_get_counters(p3d_scene* s, p3d_counters* out) {
     out->closest_queries = c.closest_queries; out->shadow_queries = c.shadow_queries;
     out->box_tests = c.box_tests; out->sphere_tests = c.sphere_tests; out->tri_tests = c.tri_tests;
     out->aabox_tests = c.aabox_tests; out->plane_tests = c.plane_tests; out->pixels = c.pixels;
+    return P3D_OK;
+}
+
+int p3d_debug_set_stamps(p3d_scene* s, void* device_buffer) {
+    if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
+    s->dbg_stamps = (unsigned long long*)device_buffer;
     return P3D_OK;
 }
 

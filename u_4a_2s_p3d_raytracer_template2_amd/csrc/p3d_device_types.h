@@ -73,6 +73,10 @@ struct LaunchParams {
     float eye[3], u[3], v[3], n[3];
     float w, h, plane_dist, aperture, focal_ratio;
     int32_t res_x, res_y;
+    // frame constants of Camera::PrimaryRay (RT/camera.h:93-95): u*w, v*h, n*(-plane_dist), and
+    // per-column / per-row tables of (x+0.5)/res_x - 0.5 and (y+0.5)/res_y - 0.5 (device, cached)
+    float uw[3], vh[3], vz[3];
+    const float* ray_fx; const float* ray_fy;
     // render
     int32_t max_depth, accel, spp;
     const float* samples;          // device copy of the host sample array or nullptr
@@ -96,6 +100,7 @@ struct LaunchParams {
     NodeRec* wf_nodes_parent;                                     // level wf_level - 1 nodes
     NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
     float* wf_accum;                                              // [local px][3] running sample sum
+    unsigned long long* dbg_stamps;   // diagnostic: per (tile, wave) 8 x u64 timestamps, or nullptr
 };
 
 }  // namespace p3d

@@ -92,7 +92,7 @@ __device__ __forceinline__ bool tile_pixel(const LaunchParams& P, int& x, int& y
 }
 
 __device__ __forceinline__ Ray camera_ray(const LaunchParams& P, int x, int y, int sample) {
-    if (P.spp == 0) return primary_ray(P, (float)x + 0.5f, (float)y + 0.5f);          // RT/main.cpp:756-772
+    if (P.spp == 0) return primary_ray_tab(P, x, y);                                  // RT/main.cpp:756-772
     const int ns = P.spp * P.spp;                                                     // RT/main.cpp:776-795
     const float4 sm = reinterpret_cast<const float4*>(P.samples)[((size_t)y * P.res_x + x) * ns + sample];
     return primary_ray_lens(P, sm.z, sm.w, sm.x, sm.y);
@@ -201,6 +201,17 @@ __device__ __forceinline__ TravCtx wave_stack(const LaunchParams& P, uint32_t ex
     return tc;
 }
 
+// diagnostic stamps (only when a stamp buffer was set with p3d_debug_set_stamps): slot k of the
+// record of (tile, wave) gets the 100 MHz real-time counter; slot 7 the hardware id registers
+__device__ __forceinline__ void stamp(const LaunchParams& P, int tile, int k) {
+    if (P.dbg_stamps && (threadIdx.x & 63) == 0) {
+        unsigned long long* r = P.dbg_stamps + ((size_t)tile * P.wg_waves + (threadIdx.x >> 6)) * 8;
+        r[k] = __builtin_amdgcn_s_memrealtime();
+        if (k == 0) r[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                           ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
+    }
+}
+
 // level 1: camera rays of one sample pass over a band of tiles
 // OCC = requested waves per SIMD (amdgpu_waves_per_eu): caps the VGPR allocation so that more
 // waves hide each other's latency, at the price of a few spilled registers.  Selected at run
@@ -217,12 +228,17 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel
     const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
     const size_t p = (size_t)row * P.res_x + x;
+    stamp(P, tile, 0);
     Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
     if (valid) ray = camera_ray(P, x, y, P.wf_sample);
+    stamp(P, tile, 1);
     const Hit h = find_closest<COUNT, PACKET>(P, sv, ray, valid, tc, ctr);
+    stamp(P, tile, 2);
     if (valid && P.hit_id && P.wf_sample == 0) P.hit_id[p] = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid;
     const NodeOut o = shade_hit<COUNT, PACKET>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr);
+    stamp(P, tile, 3);
     emit(P, sh, 1, valid, (uint32_t)p, 1.0f, o);
+    stamp(P, tile, 4);
     if (valid) flush_counters<COUNT>(P, ctr, P.wf_sample == 0 ? 1u : 0u);
 }
 
@@ -394,6 +410,13 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kern
     flush_counters<COUNT>(P, ctr, 1u);
 }
 
+// per-column / per-row factors of the pixel-centre camera rays (one launch per resolution)
+__global__ void raygen_table_kernel(float* fx, float* fy, int res_x, int res_y) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < res_x) fx[i] = fdiv((float)i + 0.5f, (float)res_x) - 0.5f;      // pixel.x / res_x - 0.5f
+    if (i < res_y) fy[i] = fdiv((float)i + 0.5f, (float)res_y) - 0.5f;
+}
+
 // ------------------------------------------------------------------ rank-0 de-interleave
 __global__ void deinterleave_kernel(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ frame,
                                     int res_x, int res_y, int row_block, int world, size_t rank_stride,
@@ -533,6 +556,11 @@ hipError_t prepare_kernels(size_t max_lds) {
     return hipSuccess;
 }
 
+hipError_t launch_raygen_table(float* fx, float* fy, int res_x, int res_y, hipStream_t stream) {
+    int n = res_x > res_y ? res_x : res_y;
+    hipLaunchKernelGGL(raygen_table_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fx, fy, res_x, res_y);
+    return hipGetLastError();
+}
 hipError_t launch_deinterleave(const void* gathered, void* frame, int res_x, int res_y, int row_block,
                                int world, size_t rank_stride, int bpp, hipStream_t stream) {
     hipLaunchKernelGGL(deinterleave_kernel, dim3(2048), dim3(256), 0, stream,

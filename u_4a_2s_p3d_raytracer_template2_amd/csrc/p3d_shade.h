@@ -83,6 +83,12 @@ __device__ __forceinline__ void light_term(V3 L, V3 lcol, V3& color, const Mtl& 
     float max1 = (0.0f < d1) ? d1 : 0.0f;                // std::max(0.0f, x)
     float max2 = (0.0f < VdotN) ? VdotN : 0.0f;
     V3 diff = mul(cmul(lcol, M.diff), max1);
+    if (M.ks == 0.0f && M.shine >= 0.0f) {
+        // spec * Ks * 0.4 is (finite * 0) * 0.4 = 0: the sum is unchanged (up to the sign of a zero),
+        // and powf is the most expensive call of the whole term
+        color = add(color, mul(diff, M.kd));
+        return;
+    }
     V3 spec = mul(cmul(lcol, M.spec), powf(max2, M.shine));
     color = add(color, add(mul(diff, M.kd), mul(mul(spec, M.ks), 0.4f)));
 }
@@ -124,7 +130,8 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
         hit_point = add(ray.o, mul(ray.d, h.t));
         normal = prim_normal(P, sv, h.ref, ray, hit_point);
         precise = add(hit_point, mul(normal, P3D_EPS));
-        normal = prim_normal(P, sv, h.ref, ray, precise);
+        // getNormal(precise_hit_point): only a sphere's normal depends on the point
+        if ((h.ref >> kRefKindShift) == 0u) normal = prim_normal(P, sv, h.ref, ray, precise);
     }
     V3 color = mk(0.0f, 0.0f, 0.0f);
     // lights in groups of 64: first every shadow query of the group (bit i = light i occluded),
@@ -205,6 +212,16 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
 }
 
 // Camera::PrimaryRay, RT/camera.h:91-108
+// the same ray from the frame constants: fx = px/res_x - 0.5f, fy = py/res_y - 0.5f come from
+// the per-column / per-row tables, uw = u*w, vh = v*h, vz = n*(-plane_dist) from the host
+__device__ __forceinline__ Ray primary_ray_tab(const LaunchParams& P, int x, int y) {
+    const float fx = P.ray_fx[x], fy = P.ray_fy[y];
+    V3 vX = mul(mk(P.uw[0], P.uw[1], P.uw[2]), fx);
+    V3 vY = mul(mk(P.vh[0], P.vh[1], P.vh[2]), fy);
+    Ray r; r.o = mk(P.eye[0], P.eye[1], P.eye[2]);
+    r.d = normalized(add(add(vX, vY), mk(P.vz[0], P.vz[1], P.vz[2])));
+    return r;
+}
 __device__ __forceinline__ Ray primary_ray(const LaunchParams& P, float px, float py) {
     V3 u = mk(P.u[0], P.u[1], P.u[2]), v = mk(P.v[0], P.v[1], P.v[2]), n = mk(P.n[0], P.n[1], P.n[2]);
     V3 vX = mul(mul(u, P.w), fdiv(px, (float)P.res_x) - 0.5f);
