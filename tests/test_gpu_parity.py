@@ -105,7 +105,7 @@ def test_device_intersectors_match_oracle_live_including_planes():
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_frame_matches_golden_fixture(frames, name, schedule):
     m = CASES[name]
-    out = gpu_render(m, counters=True, tree=(schedule == "tree"))
+    out = gpu_render(m, counters=True, tree=(schedule == "tree"), wavefront=(schedule == "wavefront"))
     compare(out, frames[name + "/rgb8"], frames[name + "/rgb32f"], frames[name + "/hit_id"], name)
     c = out["counters"]
     assert c["closest_queries"] == m["counters"]["closest_queries"], name
@@ -125,7 +125,7 @@ def test_schedules_and_scene_placements_are_bit_identical():
     HBM/L2: same bits, same ray counts."""
     for name in ("c2_mount_low_256x144_d4_bvh", "c4_mount_low_96_d6_spp2", "balls_box_128_d4_bvh", "dof_64_d4_spp4",
                  "balls_medium_128_d4_none"):
-        a = gpu_render(CASES[name], counters=True)
+        a = gpu_render(CASES[name], counters=True, wavefront=True)
         for kw in (dict(tree=True), dict(no_lds=True), dict(tree=True, no_lds=True), dict(no_packet=True),
                    dict(no_packet=True, no_lds=True)):
             b = gpu_render(CASES[name], counters=True, **kw)

@@ -46,7 +46,7 @@ for tree in ([False, True] if not a.tree else [True]):
    for occ in [int(v) for v in a.occ.split(",")]:
     for ch in [int(v) for v in a.chunks.split(",")]:
         ds.set_tuning(xcd_chunk=ch, waves_per_simd=occ)
-        kw = dict(max_depth=a.depth, accel=a.accel, tree=tree, no_lds=no_lds, no_packet=no_packet)
+        kw = dict(max_depth=a.depth, accel=a.accel, tree=tree, wavefront=not tree, no_lds=no_lds, no_packet=no_packet)
         for _ in range(5):
             ds.render_device(cam, rgb8_ptr=buf.data_ptr(), **kw)
         ds.timer_begin()

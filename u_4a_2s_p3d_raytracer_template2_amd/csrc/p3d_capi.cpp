@@ -49,7 +49,8 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU
 constexpr int kMaxDepth = 16;
-constexpr unsigned kPersistentWaves = 256 * 16;   // secondary-level launches: waves that stride over the queue
+constexpr unsigned kPersistentWaves = 256 * 16;       // deeper-level launches of LDS-resident scenes (full waves)
+constexpr unsigned kPersistentWavesNarrow = 256 * 16 * 4;   // ... of HBM-resident scenes (narrow waves, 4 per SIMD)
 
 template <typename T>
 struct DevBuf {
@@ -93,6 +94,7 @@ struct p3d_scene {
     DevBuf<PrimMeta> plane_meta;
     DevBuf<LightRec> lights;
     size_t lds_scene_limit = 24 * 1024;  // blobs up to this size are rendered from an LDS copy
+    size_t tree_blob_limit = (size_t)2 << 20;   // scenes above this use the tree schedule by default
     uint32_t packet_node_limit = 64;     // trees up to this many node pairs use the wave-wide walk
     float bg[3] = {0, 0, 0};
     uint32_t n_lights = 0, n_materials = 0;
@@ -293,7 +295,7 @@ int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, bool lds, bool 
         P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = cap(l - 1);
         P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
         size_t total = (size_t)cap(l) * kShards;
-        unsigned waves = (unsigned)std::min<size_t>((total + 63) / 64, kPersistentWaves);
+        unsigned waves = (unsigned)std::min<size_t>((total + 63) / 64, lds ? kPersistentWaves : kPersistentWavesNarrow);
         waves = std::max<unsigned>(kShards * 4, (waves / (kShards * 4)) * (kShards * 4));   // whole workgroups per shard
         HIP_TRY(launch_wf_secondary(P, count, lds, packet, s->occupancy, waves, s->stream));
     }
@@ -362,8 +364,14 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     }
     P.counters = s->d_counters;
     P.dbg_stamps = s->dbg_stamps;
+    P.wf_min_width = lds_scene ? 64 : 8;
 
-    const bool tree_requested = (prm->flags & P3D_FLAG_TREE_KERNEL) != 0;
+    // Schedule: level-by-level wavefront unless the caller forces one, or the scene does not fit an
+    // XCD's L2 (every node visit of an incoherent ray is then a long dependent miss, ray cost varies
+    // by orders of magnitude, and a level launch lasts as long as its slowest ray: measured on the
+    // 100k-triangle dragon, tree 2.46 ms vs wavefront 3.41 ms; on the 2k-triangle mount_high 0.57 vs 0.38)
+    const bool tree_requested = (prm->flags & P3D_FLAG_TREE_KERNEL) ||
+                                (!(prm->flags & P3D_FLAG_WAVEFRONT) && (size_t)s->blob_quads * 16 > s->tree_blob_limit);
     // wavefront bands: worst-case queues for a band of tile rows must fit the workspace budget
     const size_t tile_row_px = (size_t)P.tiles_x * 64 * P.wg_waves;
     const size_t wf_bpp = wavefront_bytes_per_pixel(prm->max_depth) + (prm->spp > 0 ? 12 : 0);

@@ -100,6 +100,7 @@ struct LaunchParams {
     NodeRec* wf_nodes_parent;                                     // level wf_level - 1 nodes
     NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
     float* wf_accum;                                              // [local px][3] running sample sum
+    int32_t wf_min_width;            // fewest lanes a deeper-level wave may use (64 = never narrow)
     unsigned long long* dbg_stamps;   // diagnostic: per (tile, wave) 8 x u64 timestamps, or nullptr
 };
 

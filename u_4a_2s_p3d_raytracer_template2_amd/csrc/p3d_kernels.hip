@@ -242,6 +242,18 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel
     if (valid) flush_counters<COUNT>(P, ctr, P.wf_sample == 0 ? 1u : 0u);
 }
 
+// Lanes a wave of a deeper level uses: a short queue is spread over ALL the shard's waves with
+// fewer rays each instead of filling 64-wide waves.  Deeper levels hold few, incoherent rays and
+// are bound by the latency of one wave's ray step, not by issue slots: narrow waves diverge less
+// (the step lasts as long as the slowest of its lanes) and more of them are in flight to hide
+// each other's memory latency.  Scenes served from LDS keep full waves (wf_min_width = 64):
+// there the extra waves only cost issue slots (measured: 0.14 -> 0.20 ms on config 2).
+__device__ __forceinline__ uint32_t wave_width(uint32_t count, uint32_t waves_per_shard, uint32_t min_width) {
+    uint32_t width = 64;
+    while (width > min_width && (unsigned long long)waves_per_shard * (width >> 1) >= count) width >>= 1;
+    return width;
+}
+
 // level >= 2: one queued ray per lane, persistent waves striding over the queue
 template <bool COUNT, bool LDS, bool PACKET, int OCC>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kernel(const LaunchParams P) {
@@ -253,8 +265,10 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
         // this workgroup's waves
         const uint32_t w0 = (blockIdx.x * blockDim.x) >> 6, nw = blockDim.x >> 6;
         bool any = false;
-        for (uint32_t w = w0; w < w0 + nw; w++)
-            if ((w / S) * 64u < P.wf_count_in[w % S]) any = true;
+        for (uint32_t w = w0; w < w0 + nw; w++) {
+            const uint32_t c = P.wf_count_in[w % S];
+            if ((w / S) * wave_width(c, per_shard, (uint32_t)P.wf_min_width) < c) any = true;
+        }
         if (!any) return;
     }
     const typename View<LDS>::type sv = View<LDS>::make(P);
@@ -262,9 +276,10 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
     const int lane = threadIdx.x & 63;
     const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t base = (wave_id / S) * 64u; base < sh.count_in; base += per_shard * 64u) {
+    const uint32_t width = wave_width(sh.count_in, per_shard, (uint32_t)P.wf_min_width);
+    for (uint32_t base = (wave_id / S) * width; base < sh.count_in; base += per_shard * width) {
         const uint32_t i = base + lane;
-        const bool valid = i < sh.count_in;
+        const bool valid = (uint32_t)lane < width && i < sh.count_in;
         uint32_t link = 0; float ior_1 = 1.0f;
         Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
         if (valid) {
