@@ -75,8 +75,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-step", type=int, default=8)
-    ap.add_argument("--frames-in-flight", type=int, default=2,
+    ap.add_argument("--frames-per-step", type=int, default=12)
+    ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames overlapped on separate HIP streams (each with its own scene handle "
                          "and workspace); 1 = strictly one frame after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
