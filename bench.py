@@ -97,11 +97,20 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # Rehearsal switch for a ONE-GPU box: P3D_BENCH_REHEARSAL=1 puts every rank on cuda:0 and moves
+    # the gather through host memory with gloo (RCCL refuses two ranks on one device).  It exercises
+    # the sharding / gather / de-interleave code path, not xGMI; numbers from it mean nothing.
+    rehearsal = os.environ.get("P3D_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     scene_file = scene_path("mount_low")
     hs = P.HostScene(scene_file)
@@ -148,7 +157,15 @@ def main():
         for k in range(1, F):                       # ... and the main stream continues after all frames
             main_stream.wait_stream(streams[k])
         if world > 1:
-            MG.gather_to_root(tiles, dist, rank, world, gathered)
+            if rehearsal:
+                torch.cuda.synchronize()
+                host = tiles.cpu()
+                hg = torch.zeros((world,) + tuple(host.shape), dtype=torch.uint8) if rank == 0 else None
+                MG.gather_to_root(host, dist, rank, world, hg)
+                if rank == 0:
+                    gathered.copy_(hg)
+            else:
+                MG.gather_to_root(tiles, dist, rank, world, gathered)
             if rank == 0:
                 for f in range(B):
                     ds.deinterleave(gathered[0, f].data_ptr(), frames[f].data_ptr(), W, H, ROW_BLOCK, world, 3,
@@ -186,8 +203,9 @@ def main():
     c1 = ds.counters()
     alg_bytes_l1 = c1["algorithmic_bytes"] + 3 * c1["pixels"]
 
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    rr = torch.tensor([float(my_rays)], dtype=torch.float64, device=dev)
+    red_dev = torch.device("cpu") if rehearsal else dev
+    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    rr = torch.tensor([float(my_rays)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
@@ -195,7 +213,7 @@ def main():
     rays_frame = float(rr.item())
 
     if rank == 0:
-        # the frame that was timed is the frame the parity tests check: verify against the oracle's golden
+        # the frame that was timed (all ranks' tiles stitched on rank 0 when N > 1)
         final = (frames[B - 1] if world > 1 else tiles[B - 1][:H]).cpu().numpy()
         total_rays = rays_frame * B * args.steps
         achieved = alg_bytes_l1 / (kern_ms * 1e-3) / 1e9
