@@ -219,8 +219,8 @@ def main():
         achieved = alg_bytes_l1 / (kern_ms * 1e-3) / 1e9
         traffic = None
         try:
-            prof = json.load(open(os.path.join(REPO, "profiles", "r01_v4_pmc_traffic.json")))
-            traffic = prof["kernels"]["wf_primary_kernel<false, true, false, 1>"]["hbm_bytes_per_launch_corrected"]
+            prof = json.load(open(os.path.join(REPO, "profiles", "r01_final_pmc.json")))
+            traffic = prof["kernels"]["wf_primary_kernel<false, true, true, 1>"]["hbm_bytes_per_launch_corrected"]
         except Exception:
             pass
         line = {
@@ -249,7 +249,7 @@ def main():
                          "frame_algorithmic_GBps": alg_bytes / (frame_dev_ms * 1e-3) / 1e9,
                          "note": "algorithmic bytes = 32 B/slab test + 16/48/32 B per sphere/triangle/box test + 3 B/px "
                                  "(SURVEY 8d). The 12-primitive scene is LDS-resident: `traffic` (PMC FETCH_SIZE x2 + "
-                                 "WRITE_SIZE per launch, profiles/r01_v4_pmc_traffic.json, 1-GPU whole-frame launch) is "
+                                 "WRITE_SIZE per launch, profiles/r01_final_pmc.json, 1-GPU whole-frame launch) is "
                                  "frame buffer + ray/node queues, far below the algorithmic figure (see DESIGN.md)"},
         }
         if world == 1 and not args.no_cpu_baseline:
