@@ -83,6 +83,12 @@ def lib():
             f.restype = C.c_int
             f.argtypes = [C.c_void_p, fp, fp, ip, fp]
         L.p3o_refgrid_dims.argtypes = [C.c_void_p, ip, ip]
+        # GLSL path tracer restatement (pt_oracle.cpp)
+        L.pto_base_hash.restype = C.c_uint32
+        L.pto_base_hash.argtypes = [C.c_uint32, C.c_uint32]
+        L.pto_hash_stream.argtypes = [C.c_float, C.c_int, fp, fp]
+        L.pto_sample.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, fp]
+        L.pto_render.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fp, fp]
         _lib = L
     return _lib
 
@@ -266,3 +272,30 @@ def rand_floats(seed, n):
     out = np.zeros(n, np.float32)
     lib().p3o_rand_floats(int(seed), int(n), _f(out))
     return out
+
+
+# ---- GLSL path tracer restatement (oracle/pt_oracle.cpp; PARITY UNPINNED, see its header)
+def pt_base_hash(a, b):
+    return int(lib().pto_base_hash(int(a) & 0xFFFFFFFF, int(b) & 0xFFFFFFFF))
+
+
+def pt_hash_stream(seed, n):
+    out = np.zeros((n, 3), np.float32)
+    s = np.zeros(1, np.float32)
+    lib().pto_hash_stream(float(np.float32(seed)), int(n), _f(out), _f(s))
+    return out, float(s[0])
+
+
+def pt_sample(res_x, res_y, x, y, itime, mouse=(0.0, 0.0)):
+    rgb = np.zeros(3, np.float32)
+    lib().pto_sample(int(res_x), int(res_y), int(x), int(y), float(np.float32(itime)), float(mouse[0]), float(mouse[1]), _f(rgb))
+    return rgb
+
+
+def pt_render(res_x, res_y, n_frames, time0=0.0, dt=1.0 / 60.0, threads=1, want_sum=True, mouse=(0.0, 0.0)):
+    rgba = np.zeros((res_y, res_x, 4), np.float32)
+    lin = np.zeros((res_y, res_x, 3), np.float32) if want_sum else None
+    lib().pto_render(int(res_x), int(res_y), int(n_frames), float(np.float32(time0)), float(np.float32(dt)),
+                     float(mouse[0]), float(mouse[1]), int(threads),
+                     _f(rgba), _f(lin) if want_sum else None)
+    return rgba, lin

@@ -23,6 +23,11 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, name), "libp3d_hip.so does not export %s" % name
     assert sorted(api.C_ABI_SYMBOLS) == declared
     assert L.p3d_abi_version() == 1
+    pt_header = open(os.path.join(REPO, "include", "p3d_pathtracer.h")).read()
+    pt_declared = sorted(set(re.findall(r"\b(p3d_pt_[a-z_]+)\s*\(", pt_header)))
+    assert pt_declared == sorted(api.PT_C_ABI_SYMBOLS)
+    for name in pt_declared:
+        assert hasattr(L, name), "libp3d_hip.so does not export %s" % name
 
 
 def test_missing_extension_fails_loudly(monkeypatch):

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 on one GPU: mount_low 4096x4096, depth 6, spp 2 (4 jittered samples + thin lens,
+summed and divided by 16 like the reference), host-generated libc rand() sample stream (seed 12345)."""
+import os, sys, time
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from conftest import scene_path
+import torch
+import u_4a_2s_p3d_raytracer_template2_amd as P
+res = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+hs = P.HostScene(scene_path("mount_low")); hs.set_resolution(res, res); cam = hs.camera()
+t0 = time.time(); samples = hs.samples(12345, 2); t1 = time.time()
+print("sample stream: %.2f s on the host, %.0f MB" % (t1 - t0, samples.nbytes / 1e6))
+ds = P.DeviceScene.from_host(hs)
+out = torch.zeros((res, res, 3), dtype=torch.uint8, device="cuda")
+kw = dict(max_depth=6, accel=P.ACCEL_BVH, spp=2, samples=samples)
+ds.render_device(cam, rgb8_ptr=out.data_ptr(), counters=True, **kw)
+c = ds.counters(); print("counters", c)
+for tree in (False, True):
+    for _ in range(1): ds.render_device(cam, rgb8_ptr=out.data_ptr(), tree=tree, wavefront=not tree, **kw)
+    ds.sync()
+    n = 3
+    t = time.perf_counter()
+    for _ in range(n): ds.render_device(cam, rgb8_ptr=out.data_ptr(), tree=tree, wavefront=not tree, profile=True, **kw)
+    f_ms, k_ms = ds.profile(); ds.sync()
+    wall = (time.perf_counter() - t) / n * 1e3
+    print("%s: device %.2f ms/frame (wall incl. %.0f MB sample upload %.1f ms)  %.1f Mrays/s  checksum %d" % (
+        "tree" if tree else "wavefront", f_ms, samples.nbytes / 1e6, wall, c["rays"] / f_ms / 1e3, int(out.sum().item())))

@@ -4,8 +4,8 @@ The product is csrc/ (HIP kernels, C-ABI, C++ host layer).  This package is the 
 binding that tests/ and bench.py drive it through; it holds no rendering logic and has no CPU
 fallback: importing `api` without a built libp3d_hip.so raises.
 """
-from .api import (ACCEL_BVH, ACCEL_GRID, ACCEL_NONE, Counters, DeviceScene, HostScene, P3DError,
+from .api import (PathTracer, pt_debug_hash, ACCEL_BVH, ACCEL_GRID, ACCEL_NONE, Counters, DeviceScene, HostScene, P3DError,
                   build_native, debug_intersect, device_count, host_bvh, lib, local_rows)
 
-__all__ = ["ACCEL_BVH", "ACCEL_GRID", "ACCEL_NONE", "Counters", "DeviceScene", "HostScene", "P3DError",
+__all__ = ["PathTracer", "pt_debug_hash", "ACCEL_BVH", "ACCEL_GRID", "ACCEL_NONE", "Counters", "DeviceScene", "HostScene", "P3DError",
            "build_native", "debug_intersect", "device_count", "host_bvh", "lib", "local_rows"]

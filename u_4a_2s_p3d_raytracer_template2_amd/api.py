@@ -143,8 +143,31 @@ def lib():
     L.p3dh_bvh_free.argtypes = [C.c_void_p]
     L.p3dh_bvh_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.p3dh_bvh_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.p3d_pt_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.p3d_pt_destroy.argtypes = [C.c_void_p]
+    L.p3d_pt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.p3d_pt_render.argtypes = [C.c_void_p, C.POINTER(PtParams), C.POINTER(PtOutputs)]
+    L.p3d_pt_sync.argtypes = [C.c_void_p]
+    L.p3d_pt_timer_begin.argtypes = [C.c_void_p]
+    L.p3d_pt_timer_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.p3d_pt_debug_hash.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
+
+
+class PtParams(C.Structure):
+    _fields_ = [("res_x", C.c_int32), ("res_y", C.c_int32), ("n_frames", C.c_int32), ("first_frame", C.c_int32),
+                ("frame_stride", C.c_int32), ("time0", C.c_float), ("dt", C.c_float), ("mouse_x", C.c_float),
+                ("mouse_y", C.c_float)]
+
+
+class PtOutputs(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("linear", C.c_void_p), ("memory", C.c_int32)]
+
+
+# include/p3d_pathtracer.h
+PT_C_ABI_SYMBOLS = ["p3d_pt_create", "p3d_pt_destroy", "p3d_pt_set_stream", "p3d_pt_render", "p3d_pt_sync",
+                    "p3d_pt_timer_begin", "p3d_pt_timer_end", "p3d_pt_debug_hash"]
 
 
 def _check(rc, what):
@@ -378,3 +401,64 @@ def host_bvh(desc, leaf_max=0):
     lib().p3dh_bvh_free(h)
     return {"nodes": nodes, "refs": refs, "n_leaves": int(info[2]), "max_depth": int(info[3]),
             "n_prims": int(info[4])}
+
+
+class PathTracer:
+    """The reference's Shadertoy path tracer on one GPU (include/p3d_pathtracer.h)."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _check(lib().p3d_pt_create(int(device), C.byref(self.h)), "p3d_pt_create")
+
+    def close(self):
+        if self.h:
+            lib().p3d_pt_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, ptr):
+        _check(lib().p3d_pt_set_stream(self.h, C.c_void_p(ptr)), "p3d_pt_set_stream")
+
+    def sync(self):
+        _check(lib().p3d_pt_sync(self.h), "p3d_pt_sync")
+
+    def timer_begin(self):
+        _check(lib().p3d_pt_timer_begin(self.h), "p3d_pt_timer_begin")
+
+    def timer_end(self):
+        ms = C.c_float(0)
+        _check(lib().p3d_pt_timer_end(self.h, C.byref(ms)), "p3d_pt_timer_end")
+        return ms.value
+
+    @staticmethod
+    def _params(res_x, res_y, n_frames, first_frame, frame_stride, time0, dt, mouse):
+        return PtParams(int(res_x), int(res_y), int(n_frames), int(first_frame), int(frame_stride), float(time0),
+                        float(dt), float(mouse[0]), float(mouse[1]))
+
+    def render(self, res_x, res_y, n_frames, first_frame=0, frame_stride=1, time0=0.0, dt=1.0 / 60.0, mouse=(0.0, 0.0)):
+        """Host arrays: rgba [H,W,4] (gamma-encoded running mean + frame count), linear [H,W,3] (sum)."""
+        rgba = np.zeros((res_y, res_x, 4), np.float32)
+        lin = np.zeros((res_y, res_x, 3), np.float32)
+        p = self._params(res_x, res_y, n_frames, first_frame, frame_stride, time0, dt, mouse)
+        o = PtOutputs(rgba.ctypes.data, lin.ctypes.data, 0)
+        _check(lib().p3d_pt_render(self.h, C.byref(p), C.byref(o)), "p3d_pt_render")
+        return rgba, lin
+
+    def render_device(self, rgba_ptr, linear_ptr, res_x, res_y, n_frames, first_frame=0, frame_stride=1, time0=0.0,
+                      dt=1.0 / 60.0, mouse=(0.0, 0.0)):
+        p = self._params(res_x, res_y, n_frames, first_frame, frame_stride, time0, dt, mouse)
+        o = PtOutputs(rgba_ptr or None, linear_ptr or None, 1)
+        _check(lib().p3d_pt_render(self.h, C.byref(p), C.byref(o)), "p3d_pt_render")
+
+
+def pt_debug_hash(a, b, device=0):
+    a = np.ascontiguousarray(a, np.uint32)
+    b = np.ascontiguousarray(b, np.uint32)
+    out = np.zeros(len(a), np.uint32)
+    _check(lib().p3d_pt_debug_hash(int(device), len(a), a.ctypes.data, b.ctypes.data, out.ctypes.data), "p3d_pt_debug_hash")
+    return out

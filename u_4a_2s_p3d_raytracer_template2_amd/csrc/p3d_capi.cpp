@@ -116,6 +116,8 @@ struct p3d_scene {
     int occupancy = 0;     // 0 = compiler default register budget, else 5 / 6 / 8 waves per SIMD
 };
 
+extern "C" int p3d_internal_set_error(int code, const char* msg) { g_err = msg ? msg : ""; return code; }
+
 extern "C" {
 
 int p3d_abi_version(void) { return P3D_ABI_VERSION; }

@@ -1,0 +1,330 @@
+// pt_kernels.hip -- the reference's Shadertoy path tracer (PT/P3D_RT.glsl + PT/common.glsl,
+// PT/ = /root/reference/GPU_PathTracer_template/) as one gfx950 kernel: a lane is a pixel and
+// runs ALL requested frames of mainImage() in registers (the shader's only inter-frame state is
+// the pixel's own previous value in buffer A, so nothing has to go through memory between
+// frames).  The 100 procedural small spheres are ray-independent except for the motion-blur
+// offset, so each workgroup derives their table once into LDS (same integer hash, same float
+// expressions as the shader evaluates per ray) and every hit_world() walks that table with
+// broadcast LDS reads; the pixel RNG is still advanced once per moving-sphere candidate per call,
+// exactly like the shader.  GLSL built-ins at their specification formulas; compiled with
+// -ffp-contract=off.  PARITY UNPINNED (see include/p3d_pathtracer.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "p3d_pathtracer.h"
+
+namespace p3dpt {
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 F3(float a, float b, float c) { f3 r; r.x = a; r.y = b; r.z = c; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return F3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) { return F3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+__device__ __forceinline__ float len3(f3 a) { return __builtin_sqrtf(dot3(a, a)); }
+__device__ __forceinline__ f3 norm3(f3 a) { return a / len3(a); }
+__device__ __forceinline__ f3 mix3(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ f3 pow3(f3 a, float e) { return F3(powf(a.x, e), powf(a.y, e), powf(a.z, e)); }
+
+#define PT_PI 3.14159265358979f      // PT/common.glsl:1
+#define PT_EPS 0.001f                // PT/common.glsl:2
+
+// ---- integer hash RNG, PT/common.glsl:29-54 (exact in uint32)
+__device__ __forceinline__ uint32_t base_hash(uint32_t px, uint32_t py) {
+    uint32_t qx = 1103515245U * ((px >> 1U) ^ py);
+    uint32_t qy = 1103515245U * ((py >> 1U) ^ px);
+    uint32_t h = 1103515245U * (qx ^ (qy >> 3U));
+    return h ^ (h >> 16);
+}
+__device__ __forceinline__ uint32_t next_hash(float& seed) {     // vec2(seed += 0.1, seed += 0.1): left to right
+    seed += 0.1f; const float a = seed;
+    seed += 0.1f; const float b = seed;
+    return base_hash(__float_as_uint(a), __float_as_uint(b));
+}
+__device__ __forceinline__ float hash1(float& seed) { return (float)next_hash(seed) / (float)0xffffffffU; }
+__device__ __forceinline__ f2 hash2(float& seed) {
+    const uint32_t n = next_hash(seed);
+    f2 r; r.x = (float)(n & 0x7fffffffU) / (float)0x7fffffff; r.y = (float)((n * 48271U) & 0x7fffffffU) / (float)0x7fffffff;
+    return r;
+}
+__device__ __forceinline__ f3 hash3(float& seed) {
+    const uint32_t n = next_hash(seed);
+    return F3((float)(n & 0x7fffffffU) / (float)0x7fffffff, (float)((n * 16807U) & 0x7fffffffU) / (float)0x7fffffff,
+              (float)((n * 48271U) & 0x7fffffffU) / (float)0x7fffffff);
+}
+__device__ __forceinline__ f2 random_in_unit_disk(float& seed) {                  // :71-76
+    const f2 h = hash2(seed);
+    const float phi = h.y * 6.28318530718f;
+    const float r = __builtin_sqrtf(h.x * 1.0f);
+    f2 o; o.x = r * sinf(phi); o.y = r * cosf(phi);
+    return o;
+}
+__device__ __forceinline__ f3 random_in_unit_sphere(float& seed) {                // :78-84
+    const f3 h = hash3(seed) * F3(2.0f, 6.28318530718f, 1.0f) - F3(1.0f, 0.0f, 0.0f);
+    const float phi = h.y;
+    const float r = powf(h.z, 1.0f / 3.0f);
+    const float s = __builtin_sqrtf(1.0f - h.x * h.x);
+    return F3(r * (s * sinf(phi)), r * (s * cosf(phi)), r * h.x);
+}
+
+struct Ray { f3 o, d; float t; };
+struct Cam { f3 eye, u, v, n; float width, height, lensRadius, planeDist, focusDist, time0, time1; };
+enum { MT_DIFFUSE = 0, MT_METAL = 1, MT_DIALECTRIC = 2 };
+struct Mat { int type; f3 albedo, spec; float rough, refIdx; f3 refract; };
+struct Rec { f3 pos, normal; float t; Mat m; };
+
+__device__ __forceinline__ Mat diffuse_mat(f3 albedo) { Mat m; m.type = MT_DIFFUSE; m.albedo = albedo; m.spec = F3(0, 0, 0); m.rough = 1.0f; m.refIdx = 1.0f; m.refract = F3(0, 0, 0); return m; }
+__device__ __forceinline__ Mat metal_mat(f3 spec, float rough) { Mat m; m.type = MT_METAL; m.albedo = F3(0, 0, 0); m.spec = spec; m.rough = rough; m.refIdx = 0.0f; m.refract = F3(0, 0, 0); return m; }
+__device__ __forceinline__ Mat glass_mat(f3 refract, float idx, float rough) { Mat m; m.type = MT_DIALECTRIC; m.albedo = F3(1, 1, 1); m.spec = F3(0.04f, 0.04f, 0.04f); m.refIdx = idx; m.refract = refract; m.rough = rough; return m; }
+
+// ---- primitives, PT/common.glsl:334-500
+__device__ __forceinline__ bool hit_triangle(f3 v0, f3 v1, f3 v2, const Ray& r, float tmin, float tmax, Rec& rec) {
+    const f3 e1 = v1 - v0, e2 = v2 - v0;
+    const f3 pv = cross3(r.d, e2);
+    const float det = dot3(pv, e1);
+    if (det > -0.0000001f && det < 0.0000001f) return false;
+    const float inv = 1.0f / det;
+    const f3 tv = r.o - v0;
+    const float u = inv * dot3(tv, pv);
+    if (u < 0.0f || u > 1.0f) return false;
+    const f3 qv = cross3(tv, e1);
+    const float v = inv * dot3(r.d, qv);
+    if (v < 0.0f || v > 1.0f) return false;          // (sic) PT/common.glsl:364
+    const float t = inv * dot3(e2, qv);
+    if (t < tmax && t > tmin) {
+        rec.t = t; rec.normal = norm3(cross3(e1, e2)); rec.pos = r.o + r.d * t;
+        return true;
+    }
+    return false;
+}
+// static and moving spheres share the test once the centre is known; `exact_normal` selects
+// normalize(pos - c) (hit_sphere) or (pos - c) / radius (hit_movingSphere)
+__device__ __forceinline__ bool hit_sphere(f3 c, float radius, bool moving, const Ray& r, float tmin, float tmax, Rec& rec) {
+    const f3 L = r.o - c;
+    const float b = dot3(L, r.d);
+    const float cc = dot3(L, L) - radius * radius;
+    if (cc > 0.0f && b > 0.0f) return false;
+    const float disc = b * b - cc;
+    if (disc < 0.0f) return false;
+    const float sq = __builtin_sqrtf(disc);
+    float t = -b - sq;
+    if (t < 0.0f) t = -b + sq;
+    if (t < tmax && t > tmin) {
+        rec.t = t; rec.pos = r.o + r.d * t;
+        if (radius >= 0.0f) rec.normal = moving ? ((rec.pos - c) / radius) : norm3(rec.pos - c);
+        else rec.normal = norm3(c - rec.pos);
+        return true;
+    }
+    return false;
+}
+
+// LDS table of the 10x10 procedural spheres (PT/P3D_RT.glsl:88-178): centre, class, hash seed
+struct SmallSphere { float cx, cy, cz; int cls; float seed; };   // cls: -1 absent, 0 moving, 1 diffuse, 2 metal, 3 fuzzy metal, 4 glass
+__device__ __forceinline__ void build_small_spheres(SmallSphere* tab) {
+    for (int i = threadIdx.x; i < 100; i += blockDim.x) {
+        const int x = i / 10 - 5, y = i % 10 - 5;
+        const float fx = (float)x, fy = (float)y;
+        float seed = fx + fy / 1000.0f;
+        const f3 r1 = hash3(seed);
+        const f3 c = F3(fx + 0.9f * r1.x, 0.2f, fy + 0.9f * r1.y);
+        SmallSphere s; s.cx = c.x; s.cy = c.y; s.cz = c.z; s.seed = seed;
+        if (!(len3(c - F3(4.0f, 0.2f, 0.0f)) > 0.9f)) s.cls = -1;
+        else if (r1.z < 0.3f) s.cls = 0;
+        else if (r1.z < 0.5f) s.cls = 1;
+        else if (r1.z < 0.7f) s.cls = 2;
+        else if (r1.z < 0.9f) s.cls = 3;
+        else s.cls = 4;
+        tab[i] = s;
+    }
+}
+__device__ __forceinline__ Mat small_sphere_material(int cls, float seed) {
+    if (cls <= 1) { const f3 a = hash3(seed); const f3 b = hash3(seed); return diffuse_mat(a * b); }
+    if (cls == 2) return metal_mat((hash3(seed) + F3(1.0f, 1.0f, 1.0f)) * 0.5f, 0.0f);
+    if (cls == 3) { const f3 a = (hash3(seed) + F3(1.0f, 1.0f, 1.0f)) * 0.5f; const float rg = hash1(seed); return metal_mat(a, rg); }
+    return glass_mat(hash3(seed), 1.2f, 0.0f);
+}
+
+// hit_world, PT/P3D_RT.glsl:12-180
+__device__ __forceinline__ bool hit_world(const SmallSphere* tab, float& gSeed, const Ray& r, float tmin, float tmax, Rec& rec) {
+    bool hit = false;
+    rec.t = tmax;
+    if (hit_triangle(F3(-10.0f, -0.01f, 10.0f), F3(10.0f, -0.01f, 10.0f), F3(-10.0f, -0.01f, -10.0f), r, tmin, rec.t, rec)) { hit = true; rec.m = diffuse_mat(F3(0.2f, 0.2f, 0.2f)); }
+    if (hit_triangle(F3(-10.0f, -0.01f, -10.0f), F3(10.0f, -0.01f, 10.0f), F3(10.0f, -0.01f, -10.0f), r, tmin, rec.t, rec)) { hit = true; rec.m = diffuse_mat(F3(0.2f, 0.2f, 0.2f)); }
+    if (hit_sphere(F3(-4.0f, 1.0f, 0.0f), 1.0f, false, r, tmin, rec.t, rec)) { hit = true; rec.m = diffuse_mat(F3(0.4f, 0.2f, 0.1f)); }
+    if (hit_sphere(F3(4.0f, 1.0f, 0.0f), 1.0f, false, r, tmin, rec.t, rec)) { hit = true; rec.m = metal_mat(F3(0.7f, 0.6f, 0.5f), 0.0f); }
+    if (hit_sphere(F3(0.0f, 1.0f, 0.0f), 1.0f, false, r, tmin, rec.t, rec)) { hit = true; rec.m = glass_mat(F3(0, 0, 0), 1.333f, 0.0f); }
+    if (hit_sphere(F3(0.0f, 1.0f, 0.0f), -0.5f, false, r, tmin, rec.t, rec)) { hit = true; rec.m = glass_mat(F3(0, 0, 0), 1.333f, 0.0f); }
+    int best = -1;
+    for (int i = 0; i < 100; i++) {
+        const SmallSphere s = tab[i];
+        if (s.cls < 0) continue;
+        f3 c = F3(s.cx, s.cy, s.cz);
+        bool moving = false;
+        if (s.cls == 0) {          // motion blur: centre interpolated towards a RANDOM centre1, drawn per call
+            const f3 c1 = c + F3(0.0f, hash1(gSeed) * 0.5f, 0.0f);
+            c = c + (c1 - c) * ((r.t - 0.0f) / (1.0f - 0.0f));
+            moving = true;
+        }
+        if (hit_sphere(c, 0.2f, moving, r, tmin, rec.t, rec)) { hit = true; best = i; }
+    }
+    if (best >= 0) rec.m = small_sphere_material(tab[best].cls, tab[best].seed);
+    return hit;
+}
+
+__device__ __forceinline__ float schlick(float cosine, float r0) { r0 = r0 * r0; return r0 + (1.0f - r0) * powf(1.0f - cosine, 5.0f); }
+
+// scatter, PT/common.glsl:217-324
+__device__ __forceinline__ bool scatter(float& gSeed, const Ray& in, const Rec& rec, f3& atten, Ray& out) {
+    f3 precise = rec.pos + rec.normal * PT_EPS;
+    if (rec.m.type == MT_DIFFUSE) {
+        const f3 S = rec.pos + rec.normal + norm3(random_in_unit_sphere(gSeed));
+        const f3 dir = norm3(S - rec.pos);
+        out.o = precise; out.d = norm3(dir); out.t = in.t;
+        atten = rec.m.albedo * fmaxf(dot3(out.d, rec.normal), 0.0f) / PT_PI;
+        return true;
+    }
+    if (rec.m.type == MT_METAL) {
+        f3 dir = norm3(in.d - 2.0f * dot3(in.d, rec.normal) * rec.normal);
+        dir = dir + rec.m.rough * random_in_unit_sphere(gSeed);
+        out.o = precise; out.d = dir; out.t = in.t;
+        atten = rec.m.spec;
+        return true;
+    }
+    atten = rec.m.albedo;
+    f3 outward; float niOverNt, cosine, etaI, etaT;
+    if (dot3(in.d, rec.normal) > 0.0f) {
+        outward = -rec.normal; niOverNt = rec.m.refIdx; cosine = dot3(in.d, rec.normal); etaI = rec.m.refIdx; etaT = 1.0f;
+    } else {
+        outward = rec.normal; niOverNt = 1.0f / rec.m.refIdx; cosine = -dot3(in.d, rec.normal); etaI = 1.0f; etaT = rec.m.refIdx;
+    }
+    const float r0 = (etaI - etaT) / (etaI + etaT);
+    const float k = 1.0f - niOverNt * niOverNt * (1.0f - cosine * cosine);
+    const float reflectProb = (k < 0.0f) ? 1.0f : schlick(cosine, r0);
+    if (hash1(gSeed) < reflectProb) {
+        f3 dir = in.d - 2.0f * dot3(rec.normal, in.d) * rec.normal;           // reflect()
+        dir = dir + rec.m.rough * random_in_unit_sphere(gSeed);
+        out.o = rec.pos + outward * PT_EPS; out.d = dir; out.t = in.t;         // "normalize(dir);" result unused
+    } else {
+        f3 refr = norm3(niOverNt * in.d + (niOverNt * cosine - __builtin_sqrtf(k)) * outward);
+        refr = mix3(refr, norm3(outward + random_in_unit_sphere(gSeed)), rec.m.rough * rec.m.rough);
+        const f3 ab = F3(expf(rec.m.refract.x * -rec.t), expf(rec.m.refract.y * -rec.t), expf(rec.m.refract.z * -rec.t));
+        atten = atten * ab;
+        out.o = rec.pos - outward * PT_EPS; out.d = refr; out.t = in.t;
+    }
+    return true;
+}
+
+// directlighting, PT/P3D_RT.glsl:182-232
+__device__ __forceinline__ f3 direct_lighting(const SmallSphere* tab, float& gSeed, f3 lpos, const Ray& r, const Rec& rec) {
+    f3 lightDir = norm3(lpos - rec.pos);
+    const float dotRec = fmaxf(dot3(rec.normal, lightDir), 0.0f);
+    if (!(dotRec > 0.0f)) return F3(0, 0, 0);
+    Ray feeler; feeler.o = rec.pos + PT_EPS * rec.normal; feeler.d = lightDir; feeler.t = 0.0f;
+    const float size = len3(lightDir);          // (sic) length of the normalised direction
+    Rec dummy;
+    if (hit_world(tab, gSeed, feeler, 0.0f, size, dummy)) return F3(0, 0, 0);
+    f3 specCol, diffCol; float shininess, diffuse, specular;
+    if (rec.m.type == MT_DIFFUSE) { specCol = F3(0.1f, 0.1f, 0.1f); diffCol = rec.m.albedo; shininess = 10.0f; diffuse = 1.0f; specular = 0.0f; }
+    else if (rec.m.type == MT_METAL) { specCol = rec.m.albedo; diffCol = F3(0, 0, 0); shininess = 100.0f; diffuse = 0.0f; specular = 1.0f; }
+    else { specCol = F3(0.004f, 0.004f, 0.004f); diffCol = F3(0, 0, 0); shininess = 100.0f; diffuse = 0.0f; specular = 1.0f; }
+    lightDir = norm3(lightDir);
+    const f3 H = norm3(lightDir - r.d);
+    diffCol = diffCol * fmaxf(0.0f, dot3(rec.normal, lightDir));                        // pl.color = (1,1,1)
+    specCol = specCol * powf(fmaxf(0.0f, dot3(rec.normal, H)), shininess);
+    return diffCol * diffuse + specCol * specular;
+}
+
+// rayColor, PT/P3D_RT.glsl:234-282 (MAX_BOUNCES 10, RUSSIAN_ROULETTE false)
+__device__ __forceinline__ f3 ray_color(const SmallSphere* tab, float& gSeed, Ray r) {
+    Rec rec;
+    rec.pos = F3(0, 0, 0); rec.normal = F3(0, 0, 0); rec.t = 0.0f; rec.m = diffuse_mat(F3(0, 0, 0));
+    f3 col = F3(0, 0, 0), thr = F3(1, 1, 1);
+    for (int i = 0; i < 10; ++i) {
+        if (hit_world(tab, gSeed, r, 0.001f, 10000.0f, rec)) {
+            col = col + direct_lighting(tab, gSeed, F3(-10.0f, 15.0f, 0.0f), r, rec) * thr;
+            col = col + direct_lighting(tab, gSeed, F3(8.0f, 15.0f, 3.0f), r, rec) * thr;
+            col = col + direct_lighting(tab, gSeed, F3(1.0f, 15.0f, -9.0f), r, rec) * thr;
+            Ray sr; f3 atten;
+            if (scatter(gSeed, r, rec, atten, sr)) { r = sr; thr = thr * atten; }
+        } else {
+            const float t = 0.8f * (r.d.y + 1.0f);
+            col = col + thr * mix3(F3(1, 1, 1), F3(0.5f, 0.7f, 1.0f), t);
+            break;
+        }
+    }
+    return col;
+}
+
+struct PtLaunch {
+    Cam cam;                 // createCamera() result (host, PT/common.glsl:101-128)
+    float res_x, res_y;
+    int32_t ires_x, ires_y;
+    int32_t n_frames, first_frame, frame_stride;
+    float time0, dt;
+    float* rgba; float* linear;
+};
+
+__global__ __launch_bounds__(256) void pt_frames_kernel(const PtLaunch P) {
+    __shared__ SmallSphere tab[100];
+    build_small_spheres(tab);
+    __syncthreads();
+    const int tiles_x = (P.ires_x + 15) / 16;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * 16 + (threadIdx.x & 15), y = ty * 16 + (threadIdx.x >> 4);
+    if (x >= P.ires_x || y >= P.ires_y) return;
+    const float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;                 // gl_FragCoord
+    const float pix_hash = (float)base_hash(__float_as_uint(fcx), __float_as_uint(fcy)) / (float)0xffffffffU;
+    float prev0 = 0.0f, prev1 = 0.0f, prev2 = 0.0f, prevw = 0.0f;             // buffer A texel of this pixel
+    f3 sum = F3(0, 0, 0);
+    for (int j = 0; j < P.n_frames; j++) {
+        const int k = P.first_frame + j * P.frame_stride;
+        const float iTime = P.time0 + (float)k * P.dt;
+        float gSeed = pix_hash + iTime;                                       // PT/P3D_RT.glsl:288
+        const f2 jit = hash2(gSeed);
+        const float psx = fcx + jit.x, psy = fcy + jit.y;
+        // getRay, PT/common.glsl:130-146
+        const f2 d = random_in_unit_disk(gSeed);
+        const float lsx = P.cam.lensRadius * d.x, lsy = P.cam.lensRadius * d.y;
+        const float time = P.cam.time0 + hash1(gSeed) * (P.cam.time1 - P.cam.time0);
+        const float ppx = P.cam.width * (psx / P.res_x - 0.5f) * P.cam.focusDist;
+        const float ppy = P.cam.height * (psy / P.res_y - 0.5f) * P.cam.focusDist;
+        Ray r;
+        r.o = P.cam.eye + P.cam.u * lsx + P.cam.v * lsy;
+        r.d = norm3(P.cam.u * (ppx - lsx) + P.cam.v * (ppy - lsy) + P.cam.n * (-P.cam.focusDist * P.cam.planeDist));
+        r.t = time;
+        f3 color = ray_color(tab, gSeed, r);
+        sum = sum + color;
+        // accumulation, PT/P3D_RT.glsl:345-365
+        const f3 prevLinear = pow3(F3(prev0, prev1, prev2), 2.2f);
+        const float w = prevw + 1.0f;
+        color = mix3(prevLinear, color, 1.0f / w);
+        const f3 g = pow3(color, 1.0f / 2.2f);
+        prev0 = g.x; prev1 = g.y; prev2 = g.z; prevw = w;
+    }
+    const size_t p = (size_t)y * P.ires_x + x;
+    if (P.rgba) reinterpret_cast<float4*>(P.rgba)[p] = make_float4(prev0, prev1, prev2, prevw);
+    if (P.linear) { P.linear[3 * p] = sum.x; P.linear[3 * p + 1] = sum.y; P.linear[3 * p + 2] = sum.z; }
+}
+
+__global__ void pt_hash_kernel(uint32_t n, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = base_hash(a[i], b[i]);
+}
+
+hipError_t launch_pt_frames(const PtLaunch& P, hipStream_t stream) {
+    const int tiles = ((P.ires_x + 15) / 16) * ((P.ires_y + 15) / 16);
+    hipLaunchKernelGGL(pt_frames_kernel, dim3(tiles), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
+hipError_t launch_pt_hash(uint32_t n, const uint32_t* a, const uint32_t* b, uint32_t* out, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_hash_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, a, b, out);
+    return hipGetLastError();
+}
+
+}  // namespace p3dpt
