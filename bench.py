@@ -70,6 +70,78 @@ def cpu_baseline(scene_file, budget_s=20.0):
     return out
 
 
+def bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, rehearsal):
+    """BASELINE config 5: the Shadertoy path tracer, 1920x1080, --spp samples per pixel per step.
+    One step = one converged image.  N > 1: rank r traces samples r, r+N, ... (weak in samples per
+    pixel would change the image, so the image is fixed: strong scaling) and the linear sums are
+    reduced to rank 0 with one RCCL reduce."""
+    W, H = RES
+    spp = args.spp
+    if spp % world:
+        raise SystemExit("--spp must be a multiple of --gpus")
+    pt = P.PathTracer(device=local_rank)
+    pt.set_stream(torch.cuda.current_stream().cuda_stream)
+    lin = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+
+    def step():
+        pt.render_device(0, lin.data_ptr(), W, H, spp // world, first_frame=rank, frame_stride=world)
+        if world > 1:
+            if rehearsal:
+                torch.cuda.synchronize()
+                h = lin.cpu()
+                dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    lin.copy_(h)
+            else:
+                dist.reduce(lin, dst=0, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    red_dev = torch.device("cpu") if rehearsal else dev
+    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt_max = float(tt.item())
+    if rank == 0:
+        img = torch.nan_to_num(lin / spp).clamp(0, None).pow(1 / 2.2)
+        line = {
+            "metric": "Msamples/s (paths) + ms/image @1920x1080 %d spp" % spp,
+            "value": W * H * spp * args.steps / dt_max / 1e6, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic: the procedural scene of GPU_PathTracer_template/P3D_RT.glsl (no mouse, iTime = k/60)",
+            "config": {"workload": "P3D_RT.glsl path tracer 1920x1080 %d spp (BASELINE config 5)" % spp,
+                       "parallelism": "1 GPU" if world == 1 else "%d GPUs: samples split, RCCL sum-reduce to rank 0" % world,
+                       "image_mean": float(img.mean().item())},
+            "roofline": None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_py as O
+            w, h, n = 240, 135, 4
+            t = time.perf_counter()
+            O.pt_render(w, h, n, threads=1, want_sum=False)
+            el = time.perf_counter() - t
+            line["cpu_baseline"] = {"value": w * h * n / el / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                    "sample": "%dx%d, %d samples per pixel, single thread: %.1f s" % (w, h, n, el)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    pt.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +152,10 @@ def main():
                     help="independent frames overlapped on separate HIP streams (each with its own scene handle "
                          "and workspace); 1 = strictly one frame after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["config2", "pathtracer"], default="config2",
+                    help="config2 = the headline Whitted frame; pathtracer = BASELINE config 5 (P3D_RT.glsl scene, "
+                         "1920x1080, --spp samples per step, samples split across ranks + RCCL sum-reduce)")
+    ap.add_argument("--spp", type=int, default=256, help="pathtracer workload: samples (frames) per step")
     args = ap.parse_args()
 
     import torch
@@ -111,6 +187,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.workload == "pathtracer":
+        return bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, rehearsal)
 
     scene_file = scene_path("mount_low")
     hs = P.HostScene(scene_file)
