@@ -151,7 +151,7 @@ __device__ __forceinline__ Mat small_sphere_material(int cls, float seed) {
 }
 
 // hit_world, PT/P3D_RT.glsl:12-180
-__device__ __forceinline__ bool hit_world(const SmallSphere* tab, float& gSeed, const Ray& r, float tmin, float tmax, Rec& rec) {
+__device__ __forceinline__ bool hit_world(const SmallSphere* tab, int* wave_union, float& gSeed, const Ray& r, float tmin, float tmax, Rec& rec) {
     bool hit = false;
     rec.t = tmax;
     if (hit_triangle(F3(-10.0f, -0.01f, 10.0f), F3(10.0f, -0.01f, 10.0f), F3(-10.0f, -0.01f, -10.0f), r, tmin, rec.t, rec)) { hit = true; rec.m = diffuse_mat(F3(0.2f, 0.2f, 0.2f)); }
@@ -160,18 +160,73 @@ __device__ __forceinline__ bool hit_world(const SmallSphere* tab, float& gSeed, 
     if (hit_sphere(F3(4.0f, 1.0f, 0.0f), 1.0f, false, r, tmin, rec.t, rec)) { hit = true; rec.m = metal_mat(F3(0.7f, 0.6f, 0.5f), 0.0f); }
     if (hit_sphere(F3(0.0f, 1.0f, 0.0f), 1.0f, false, r, tmin, rec.t, rec)) { hit = true; rec.m = glass_mat(F3(0, 0, 0), 1.333f, 0.0f); }
     if (hit_sphere(F3(0.0f, 1.0f, 0.0f), -0.5f, false, r, tmin, rec.t, rec)) { hit = true; rec.m = glass_mat(F3(0, 0, 0), 1.333f, 0.0f); }
-    int best = -1;
-    for (int i = 0; i < 100; i++) {
-        const SmallSphere s = tab[i];
-        if (s.cls < 0) continue;
-        f3 c = F3(s.cx, s.cy, s.cz);
-        bool moving = false;
-        if (s.cls == 0) {          // motion blur: centre interpolated towards a RANDOM centre1, drawn per call
-            const f3 c1 = c + F3(0.0f, hash1(gSeed) * 0.5f, 0.0f);
-            c = c + (c1 - c) * ((r.t - 0.0f) / (1.0f - 0.0f));
-            moving = true;
+    // Small spheres: conservative WAVE-LEVEL culling that never changes the result.  A sphere of the
+    // 10x10 field lives in y in [0, 0.9] (radius 0.2, motion blur lifts a centre by at most 0.5) and its
+    // centre in [fx, fx+0.9] x [fz, fz+0.9].  Each lane bounds the cells its ray segment [tmin, rec.t]
+    // can touch inside that slab (margins of 0.05+ dwarf any rounding); the wave takes the union of
+    // the 64 ranges (butterfly min/max) and tests only those cells -- a scalar branch per candidate,
+    // no divergence.  Rays whose direction is not unit length (fuzzy metals add an offset without
+    // re-normalising, and the shader's sphere test assumes |d| = 1) are not geometric: they keep the
+    // whole field.  The pixel RNG is advanced for EVERY moving-sphere candidate, in index order, as
+    // the shader does.
+    int ix0 = 100, ix1 = -100, iz0 = 100, iz1 = -100;             // empty range
+    {
+        const float dd = dot3(r.d, r.d);
+        if (!(fabsf(dd - 1.0f) < 1e-3f)) { ix0 = -5; ix1 = 4; iz0 = -5; iz1 = 4; }
+        else {
+            float ta = tmin, tb = rec.t;
+            const float ylo = -0.05f, yhi = 0.95f;
+            if (r.d.y != 0.0f) {
+                const float inv = 1.0f / r.d.y;
+                const float t0 = (ylo - r.o.y) * inv, t1 = (yhi - r.o.y) * inv;
+                ta = fmaxf(ta, fminf(t0, t1)); tb = fminf(tb, fmaxf(t0, t1));
+            } else if (!(r.o.y >= ylo && r.o.y <= yhi)) tb = ta - 1.0f;
+            if (ta <= tb) {
+                const float xa = r.o.x + r.d.x * ta, xb = r.o.x + r.d.x * tb;
+                const float za = r.o.z + r.d.z * ta, zb = r.o.z + r.d.z * tb;
+                const float m = 0.25f + 0.01f * (fabsf(ta) + fabsf(tb));      // radius + slack growing with distance
+                ix0 = max(-5, (int)floorf(fminf(xa, xb) - m - 0.9f)); ix1 = min(4, (int)floorf(fmaxf(xa, xb) + m));
+                iz0 = max(-5, (int)floorf(fminf(za, zb) - m - 0.9f)); iz1 = min(4, (int)floorf(fmaxf(za, zb) + m));
+            }
         }
-        if (hit_sphere(c, 0.2f, moving, r, tmin, rec.t, rec)) { hit = true; best = i; }
+    }
+    {   // union over the ACTIVE lanes of the wave.  hit_world() is reached in divergent control flow, so
+        // a shuffle butterfly would mix in stale registers of inactive lanes and miss active ones;
+        // LDS min/max atomics on this wave's four scratch words are exact for any exec mask (DS
+        // operations of one wave execute in issue order; the wave barriers only pin the compiler).
+        int* u = wave_union + (threadIdx.x >> 6) * 4;
+        const int lane = (int)(threadIdx.x & 63);
+        if (lane == __builtin_amdgcn_readfirstlane(lane)) { u[0] = 100; u[1] = -100; u[2] = 100; u[3] = -100; }
+        __builtin_amdgcn_wave_barrier();
+        atomicMin(&u[0], ix0); atomicMax(&u[1], ix1); atomicMin(&u[2], iz0); atomicMax(&u[3], iz1);
+        __builtin_amdgcn_wave_barrier();
+        ix0 = __builtin_amdgcn_readfirstlane(((volatile int*)u)[0]); ix1 = __builtin_amdgcn_readfirstlane(((volatile int*)u)[1]);
+        iz0 = __builtin_amdgcn_readfirstlane(((volatile int*)u)[2]); iz1 = __builtin_amdgcn_readfirstlane(((volatile int*)u)[3]);
+        __builtin_amdgcn_wave_barrier();
+    }
+    int best = -1;
+    for (int gx = -5; gx < 5; gx++) {
+        const bool xin = gx >= ix0 && gx <= ix1;
+        for (int gz = -5; gz < 5; gz++) {
+            const int i = (gx + 5) * 10 + (gz + 5);
+            const int cls = __builtin_amdgcn_readfirstlane(tab[i].cls);
+            if (cls < 0) continue;
+            const bool near = xin && gz >= iz0 && gz <= iz1;          // wave-uniform
+            float h = 0.0f;
+            if (cls == 0) {        // motion blur: centre interpolated towards a RANDOM centre1, drawn per call
+                gSeed += 0.1f; const float sa = gSeed;
+                gSeed += 0.1f; const float sb = gSeed;
+                if (near) h = (float)base_hash(__float_as_uint(sa), __float_as_uint(sb)) / (float)0xffffffffU;   // hash1(gSeed)
+            }
+            if (!near) continue;
+            const SmallSphere s = tab[i];
+            f3 c = F3(s.cx, s.cy, s.cz);
+            if (cls == 0) {
+                const f3 c1 = c + F3(0.0f, h * 0.5f, 0.0f);
+                c = c + (c1 - c) * ((r.t - 0.0f) / (1.0f - 0.0f));
+            }
+            if (hit_sphere(c, 0.2f, cls == 0, r, tmin, rec.t, rec)) { hit = true; best = i; }
+        }
     }
     if (best >= 0) rec.m = small_sphere_material(tab[best].cls, tab[best].seed);
     return hit;
@@ -221,14 +276,14 @@ __device__ __forceinline__ bool scatter(float& gSeed, const Ray& in, const Rec& 
 }
 
 // directlighting, PT/P3D_RT.glsl:182-232
-__device__ __forceinline__ f3 direct_lighting(const SmallSphere* tab, float& gSeed, f3 lpos, const Ray& r, const Rec& rec) {
+__device__ __forceinline__ f3 direct_lighting(const SmallSphere* tab, int* wave_union, float& gSeed, f3 lpos, const Ray& r, const Rec& rec) {
     f3 lightDir = norm3(lpos - rec.pos);
     const float dotRec = fmaxf(dot3(rec.normal, lightDir), 0.0f);
     if (!(dotRec > 0.0f)) return F3(0, 0, 0);
     Ray feeler; feeler.o = rec.pos + PT_EPS * rec.normal; feeler.d = lightDir; feeler.t = 0.0f;
     const float size = len3(lightDir);          // (sic) length of the normalised direction
     Rec dummy;
-    if (hit_world(tab, gSeed, feeler, 0.0f, size, dummy)) return F3(0, 0, 0);
+    if (hit_world(tab, wave_union, gSeed, feeler, 0.0f, size, dummy)) return F3(0, 0, 0);
     f3 specCol, diffCol; float shininess, diffuse, specular;
     if (rec.m.type == MT_DIFFUSE) { specCol = F3(0.1f, 0.1f, 0.1f); diffCol = rec.m.albedo; shininess = 10.0f; diffuse = 1.0f; specular = 0.0f; }
     else if (rec.m.type == MT_METAL) { specCol = rec.m.albedo; diffCol = F3(0, 0, 0); shininess = 100.0f; diffuse = 0.0f; specular = 1.0f; }
@@ -241,15 +296,15 @@ __device__ __forceinline__ f3 direct_lighting(const SmallSphere* tab, float& gSe
 }
 
 // rayColor, PT/P3D_RT.glsl:234-282 (MAX_BOUNCES 10, RUSSIAN_ROULETTE false)
-__device__ __forceinline__ f3 ray_color(const SmallSphere* tab, float& gSeed, Ray r) {
+__device__ __forceinline__ f3 ray_color(const SmallSphere* tab, int* wave_union, float& gSeed, Ray r) {
     Rec rec;
     rec.pos = F3(0, 0, 0); rec.normal = F3(0, 0, 0); rec.t = 0.0f; rec.m = diffuse_mat(F3(0, 0, 0));
     f3 col = F3(0, 0, 0), thr = F3(1, 1, 1);
     for (int i = 0; i < 10; ++i) {
-        if (hit_world(tab, gSeed, r, 0.001f, 10000.0f, rec)) {
-            col = col + direct_lighting(tab, gSeed, F3(-10.0f, 15.0f, 0.0f), r, rec) * thr;
-            col = col + direct_lighting(tab, gSeed, F3(8.0f, 15.0f, 3.0f), r, rec) * thr;
-            col = col + direct_lighting(tab, gSeed, F3(1.0f, 15.0f, -9.0f), r, rec) * thr;
+        if (hit_world(tab, wave_union, gSeed, r, 0.001f, 10000.0f, rec)) {
+            col = col + direct_lighting(tab, wave_union, gSeed, F3(-10.0f, 15.0f, 0.0f), r, rec) * thr;
+            col = col + direct_lighting(tab, wave_union, gSeed, F3(8.0f, 15.0f, 3.0f), r, rec) * thr;
+            col = col + direct_lighting(tab, wave_union, gSeed, F3(1.0f, 15.0f, -9.0f), r, rec) * thr;
             Ray sr; f3 atten;
             if (scatter(gSeed, r, rec, atten, sr)) { r = sr; thr = thr * atten; }
         } else {
@@ -272,6 +327,7 @@ struct PtLaunch {
 
 __global__ __launch_bounds__(256) void pt_frames_kernel(const PtLaunch P) {
     __shared__ SmallSphere tab[100];
+    __shared__ int wave_union[4 * 4];      // per wave: cell range union scratch (hit_world)
     build_small_spheres(tab);
     __syncthreads();
     const int tiles_x = (P.ires_x + 15) / 16;
@@ -298,7 +354,7 @@ __global__ __launch_bounds__(256) void pt_frames_kernel(const PtLaunch P) {
         r.o = P.cam.eye + P.cam.u * lsx + P.cam.v * lsy;
         r.d = norm3(P.cam.u * (ppx - lsx) + P.cam.v * (ppy - lsy) + P.cam.n * (-P.cam.focusDist * P.cam.planeDist));
         r.t = time;
-        f3 color = ray_color(tab, gSeed, r);
+        f3 color = ray_color(tab, wave_union, gSeed, r);
         sum = sum + color;
         // accumulation, PT/P3D_RT.glsl:345-365
         const f3 prevLinear = pow3(F3(prev0, prev1, prev2), 2.2f);
