@@ -70,7 +70,7 @@ __device__ __forceinline__ bool light_occluded(const LaunchParams& P, const SV& 
     Ray sr; sr.o = precise; sr.d = L;
     float length = 0.0f;
     const bool bounded = P.accel != 0;
-    if (bounded) { length = vlen(sr.d); sr.d = normalized(sr.d); }
+    if (bounded && need) { length = vlen(sr.d); sr.d = normalized(sr.d); }
     if (PACKET) return any_hit_packet<COUNT>(P, sv, sr, need, bounded, length, tc.wave, ctr);
     return need ? any_hit<COUNT>(P, sv, sr, bounded, length, tc.lane, ctr) : false;
 }
@@ -125,6 +125,10 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
     o.ret = o.color;
     o.refl.o = o.color; o.refl.d = o.color; o.refr.o = o.color; o.refr.d = o.color;
     const bool hit = live && h.ref != 0xFFFFFFFFu;
+    if (__ballot(hit) == 0) {                     // whole wave missed (sky tiles): nothing to light
+        o.ret = mk(P.bg[0], P.bg[1], P.bg[2]);
+        return o;
+    }
     V3 hit_point = o.color, normal = o.color, precise = o.color;
     if (hit) {                                                           // RT/main.cpp:587-590
         hit_point = add(ray.o, mul(ray.d, h.t));
