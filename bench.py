@@ -70,6 +70,36 @@ def cpu_baseline(scene_file, budget_s=20.0):
     return out
 
 
+def cpu_baseline_synthetic(n_prims, budget_s=25.0):
+    """Synthetic scaling scene: the brute-force fall-through of the reference is O(N) per ray, so the
+    sample is a 96x54 frame (1/400 of the pixels) of the same scene, single-threaded with the reference
+    structure, plus the break-fixed all-core variant at 480x270.  Only up to 2e5 primitives (the oracle
+    reads .p3f text)."""
+    if n_prims > 200000:
+        return {"value": None, "unit": "Mrays/s", "cores": 1, "kind": "port",
+                "sample": "not run: the oracle loads .p3f text and its reference-structure closest hit is O(N) per ray"}
+    import tempfile
+    from oracle import oracle_py as O
+    from u_4a_2s_p3d_raytracer_template2_amd import synthetic as SY
+    path = os.path.join(tempfile.mkdtemp(prefix="p3d_bench_"), "synthetic.p3f")
+    SY.write_p3f(path, n_prims, 96, 54)
+    sc = O.Scene(path)
+    t0 = time.perf_counter()
+    r = sc.render(max_depth=MAX_DEPTH, accel=2, threads=1, want_f32=False, want_hit=False)
+    st = time.perf_counter() - t0
+    out = {"value": r["counters"]["rays"] / st / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+           "sample": "one 96x54 depth-4 frame of the same scene, single thread, reference structure; %.2f s" % st}
+    if st < budget_s:
+        ncpu = os.cpu_count() or 1
+        sc.set_resolution(480, 270)
+        t0 = time.perf_counter()
+        r = sc.render(max_depth=MAX_DEPTH, accel=2, threads=ncpu, break_fixed=1, want_f32=False, want_hit=False)
+        mt = time.perf_counter() - t0
+        out["multithread"] = {"value": r["counters"]["rays"] / mt / 1e6, "unit": "Mrays/s", "cores": ncpu,
+                              "note": "fall-through removed (reference BVH only) + all host cores, 480x270; %.3f s" % mt}
+    return out
+
+
 def bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, rehearsal):
     """BASELINE config 5: the Shadertoy path tracer, 1920x1080, --spp samples per pixel per step.
     One step = one converged image.  N > 1: rank r traces samples r, r+N, ... (weak in samples per
@@ -152,9 +182,17 @@ def main():
                     help="independent frames overlapped on separate HIP streams (each with its own scene handle "
                          "and workspace); 1 = strictly one frame after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["config2", "pathtracer"], default="config2",
+    ap.add_argument("--workload", choices=["config2", "pathtracer", "synthetic"], default="config2",
                     help="config2 = the headline Whitted frame; pathtracer = BASELINE config 5 (P3D_RT.glsl scene, "
-                         "1920x1080, --spp samples per step, samples split across ranks + RCCL sum-reduce)")
+                         "1920x1080, --spp samples per step, samples split across ranks + RCCL sum-reduce); "
+                         "synthetic = the SURVEY 8d scaling scene (--prims random spheres+triangles, HBM-resident BVH), "
+                         "same camera / resolution / depth as config 2")
+    ap.add_argument("--prims", type=int, default=1000000, help="synthetic workload: number of primitives")
+    ap.add_argument("--schedule", choices=["default", "wavefront", "tree"], default="default",
+                    help="force a kernel schedule (default: the library's choice)")
+    ap.add_argument("--pmc-json", default=None,
+                    help="PMC summary (tools/pmc_summary.py) to take roofline.traffic from; default: the committed one "
+                         "for the workload under profiles/")
     ap.add_argument("--spp", type=int, default=256, help="pathtracer workload: samples (frames) per step")
     args = ap.parse_args()
 
@@ -191,10 +229,23 @@ def main():
     if args.workload == "pathtracer":
         return bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, rehearsal)
 
-    scene_file = scene_path("mount_low")
-    hs = P.HostScene(scene_file)
-    hs.set_resolution(*RES)
-    cam = hs.camera()
+    synthetic = args.workload == "synthetic"
+    sched = {"wavefront": {"wavefront": True}, "tree": {"tree": True}}.get(args.schedule, {})
+    if synthetic:
+        import tempfile
+        from u_4a_2s_p3d_raytracer_template2_amd import synthetic as SY, api as API
+        scene_file = None
+        cam_file = os.path.join(tempfile.mkdtemp(prefix="p3d_bench_"), "camera.p3f")
+        cam = P.HostScene(SY.camera_p3f(cam_file, *RES)).camera()
+        t_b = time.time()
+        desc, keep = API.make_desc(*SY.arrays(args.prims))
+        make_handle = lambda: P.DeviceScene(desc, device=local_rank, keepalive=keep)
+    else:
+        scene_file = scene_path("mount_low")
+        hs = P.HostScene(scene_file)
+        hs.set_resolution(*RES)
+        cam = hs.camera()
+        make_handle = lambda: P.DeviceScene.from_host(hs, device=local_rank)
     # The deeper tree levels of one 1080p frame are too few rays to fill 256 CUs (each level launch is
     # bounded by single-wave latency), so consecutive frames -- independent work, exactly like the
     # reference's render-another-image loop -- are overlapped on F streams, one scene handle each.
@@ -203,7 +254,7 @@ def main():
     streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
     handles = []
     for st in streams:
-        h = P.DeviceScene.from_host(hs, device=local_rank)
+        h = make_handle()
         h.set_stream(st.cuda_stream)
         handles.append(h)
     ds = handles[0]
@@ -221,7 +272,7 @@ def main():
 
     # work counters of this rank's share of one frame (counting build, same traversal)
     ds.render_device(cam, rgb8_ptr=tiles[0].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
-                     rank=rank, world=world, row_block=ROW_BLOCK, counters=True)
+                     rank=rank, world=world, row_block=ROW_BLOCK, **sched, counters=True)
     ctr = ds.counters()
     my_rays = ctr["rays"]
     px_local = ctr["pixels"]
@@ -232,7 +283,7 @@ def main():
             streams[k].wait_stream(main_stream)
         for f in range(B):
             handles[f % F].render_device(cam, rgb8_ptr=tiles[f].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
-                                         rank=rank, world=world, row_block=ROW_BLOCK)
+                                         rank=rank, world=world, row_block=ROW_BLOCK, **sched)
         for k in range(1, F):                       # ... and the main stream continues after all frames
             main_stream.wait_stream(streams[k])
         if world > 1:
@@ -270,7 +321,7 @@ def main():
     frame_ms_sum = kern_ms_sum = 0.0
     for _ in range(nl):
         ds.render_device(cam, rgb8_ptr=tiles[0].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
-                         rank=rank, world=world, row_block=ROW_BLOCK, profile=True)
+                         rank=rank, world=world, row_block=ROW_BLOCK, **sched, profile=True)
         f_ms, k_ms = ds.profile()
         frame_ms_sum += f_ms
         kern_ms_sum += k_ms
@@ -278,7 +329,7 @@ def main():
     frame_dev_ms = frame_ms_sum / nl
     # level-1 work of this rank's rows = a depth-1 frame (primary closest hits + their shadow queries)
     ds.render_device(cam, rgb8_ptr=tiles[0].data_ptr(), max_depth=1, accel=P.ACCEL_BVH,
-                     rank=rank, world=world, row_block=ROW_BLOCK, counters=True)
+                     rank=rank, world=world, row_block=ROW_BLOCK, **sched, counters=True)
     c1 = ds.counters()
     alg_bytes_l1 = c1["algorithmic_bytes"] + 3 * c1["pixels"]
 
@@ -297,9 +348,15 @@ def main():
         total_rays = rays_frame * B * args.steps
         achieved = alg_bytes_l1 / (kern_ms * 1e-3) / 1e9
         traffic = None
+        stats = ds.stats()
+        dominant = "whitted_tree_kernel" if ds.last_schedule() == "tree" else "wf_primary_kernel"
+        pmc_file = args.pmc_json or os.path.join(REPO, "profiles", "r01_synthetic_%d_pmc.json" % args.prims if synthetic
+                                                 else "r01_final_pmc.json")
         try:
-            prof = json.load(open(os.path.join(REPO, "profiles", "r01_final_pmc.json")))
-            traffic = prof["kernels"]["wf_primary_kernel<false, true, true, 1>"]["hbm_bytes_per_launch_corrected"]
+            prof = json.load(open(pmc_file))
+            for name, e in prof["kernels"].items():
+                if dominant in name and "hbm_bytes_per_launch_corrected" in e:
+                    traffic = e["hbm_bytes_per_launch_corrected"]
         except Exception:
             pass
         line = {
@@ -313,26 +370,33 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic: P3D_Scenes/mount_low.p3f (12 primitives, 1 light) resolution/accel overridden to the config",
-            "config": {"workload": "mount_low.p3f 1920x1080 depth 4 BVH (BASELINE config 2)",
+            "data": ("synthetic: %d random spheres+triangles (SURVEY 8d scaling scene, seed 2024), mount_low camera" % args.prims)
+                    if synthetic else
+                    "synthetic: P3D_Scenes/mount_low.p3f (12 primitives, 1 light) resolution/accel overridden to the config",
+            "config": {"workload": ("SURVEY 8d scaling scene, %d primitives, 1920x1080 depth 4 BVH" % args.prims) if synthetic
+                       else "mount_low.p3f 1920x1080 depth 4 BVH (BASELINE config 2)",
                        "frames_per_step": B, "frames_in_flight": F, "rays_per_frame": int(rays_frame),
                        "row_block": ROW_BLOCK,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved 16-row blocks + RCCL gather to rank 0" % world,
                        "frame_checksum": int(final.astype(np.uint64).sum())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "wf_primary_kernel", "kernel_ms": kern_ms,
+                         "kernel": dominant, "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": int(alg_bytes_l1),
                          "frame_device_ms": frame_dev_ms,
                          "frame_algorithmic_bytes": int(alg_bytes),
                          "frame_algorithmic_GBps": alg_bytes / (frame_dev_ms * 1e-3) / 1e9,
-                         "note": "algorithmic bytes = 32 B/slab test + 16/48/32 B per sphere/triangle/box test + 3 B/px "
+                         "note": ("algorithmic bytes = 32 B/slab test + 16/48/32 B per sphere/triangle/box test + 3 B/px "
+                                  "(SURVEY 8d); scene read from HBM/L2 (%d MB on the device); `traffic` = PMC FETCH_SIZE x2 + "
+                                  "WRITE_SIZE per launch from %s" % (stats["device_bytes"] >> 20, os.path.basename(pmc_file)))
+                                 if synthetic else
+                                 "algorithmic bytes = 32 B/slab test + 16/48/32 B per sphere/triangle/box test + 3 B/px "
                                  "(SURVEY 8d). The 12-primitive scene is LDS-resident: `traffic` (PMC FETCH_SIZE x2 + "
                                  "WRITE_SIZE per launch, profiles/r01_final_pmc.json, 1-GPU whole-frame launch) is "
                                  "frame buffer + ray/node queues, far below the algorithmic figure (see DESIGN.md)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scene_file)
+            line["cpu_baseline"] = cpu_baseline_synthetic(args.prims) if synthetic else cpu_baseline(scene_file)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -186,6 +186,10 @@ int p3d_set_tuning(p3d_scene* scene, int32_t xcd_chunk, int32_t workspace_mib, i
  * the first sample / band. HIP events on the scene's stream. */
 int p3d_get_profile(p3d_scene* scene, float* frame_ms, float* kernel_ms);
 
+/* Kernel schedule the most recent p3d_render() of this scene used: 0 = wavefront (level kernels),
+ * 1 = tree (one launch). P3D_ERR_STATE before the first render. */
+int p3d_last_schedule(p3d_scene* scene, int32_t* schedule);
+
 /* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the
  * scene's own stream. */
 int p3d_set_stream(p3d_scene* scene, void* hip_stream);

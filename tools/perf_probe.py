@@ -25,15 +25,26 @@ ap.add_argument("--tree", action="store_true")
 ap.add_argument("--occ", default="0")
 ap.add_argument("--eye", nargs=3, type=float, default=None)
 ap.add_argument("--f32", action="store_true")
+ap.add_argument("--synthetic", type=int, default=0, help="N primitives of the SURVEY 8d scaling scene instead of a .p3f")
 a = ap.parse_args()
 
 import torch  # noqa: E402
-hs = P.HostScene(scene_path(a.scene))
-hs.set_resolution(*a.res)
-if a.eye:
-    hs.set_eye(*a.eye)
-cam = hs.camera()
-ds = P.DeviceScene.from_host(hs, leaf_max=a.leaf)
+import time  # noqa: E402
+if a.synthetic:
+    from u_4a_2s_p3d_raytracer_template2_amd import synthetic as S, api  # noqa: E402
+    hs = P.HostScene(S.camera_p3f("/tmp/synth_camera.p3f", *a.res))
+    cam = hs.camera()
+    desc, keep = api.make_desc(*S.arrays(a.synthetic))
+    t0 = time.time()
+    ds = P.DeviceScene(desc, leaf_max=a.leaf, keepalive=keep)
+    print("scene_create %.2f s" % (time.time() - t0))
+else:
+    hs = P.HostScene(scene_path(a.scene))
+    hs.set_resolution(*a.res)
+    if a.eye:
+        hs.set_eye(*a.eye)
+    cam = hs.camera()
+    ds = P.DeviceScene.from_host(hs, leaf_max=a.leaf)
 print("stats", ds.stats())
 buf = torch.zeros((a.res[1] + 16, a.res[0], 3), dtype=torch.uint8, device="cuda")
 ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=a.depth, accel=a.accel, counters=True)

@@ -76,7 +76,7 @@ class SceneStats(C.Structure):
 # every symbol include/p3d_hip.h declares (tests check that the library exports them all)
 C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_scene_create",
                  "p3d_scene_destroy", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
-                 "p3d_get_counters", "p3d_get_profile", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end",
+                 "p3d_get_counters", "p3d_get_profile", "p3d_last_schedule", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end",
                  "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_set_stamps"]
 
 
@@ -120,6 +120,7 @@ def lib():
     L.p3d_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.p3d_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.p3d_get_profile.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.p3d_last_schedule.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.p3d_set_tuning.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.p3d_timer_begin.argtypes = [C.c_void_p]
     L.p3d_timer_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -327,6 +328,12 @@ class DeviceScene:
         f, k = C.c_float(0), C.c_float(0)
         _check(lib().p3d_get_profile(self.h, C.byref(f), C.byref(k)), "p3d_get_profile")
         return f.value, k.value
+
+    def last_schedule(self):
+        """'wavefront' or 'tree': the kernel schedule of the most recent render."""
+        v = C.c_int32()
+        _check(lib().p3d_last_schedule(self.h, C.byref(v)), "p3d_last_schedule")
+        return "tree" if v.value else "wavefront"
 
     def debug_set_stamps(self, ptr):
         _check(lib().p3d_debug_set_stamps(self.h, C.c_void_p(ptr or None)), "p3d_debug_set_stamps")

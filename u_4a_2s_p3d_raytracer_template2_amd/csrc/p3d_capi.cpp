@@ -94,6 +94,7 @@ struct p3d_scene {
     DevBuf<PrimMeta> plane_meta;
     DevBuf<LightRec> lights;
     size_t lds_scene_limit = 24 * 1024;  // blobs up to this size are rendered from an LDS copy
+    int last_schedule = -1;
     size_t tree_blob_limit = (size_t)2 << 20;   // scenes above this use the tree schedule by default
     uint32_t packet_node_limit = 64;     // trees up to this many node pairs use the wave-wide walk
     float bg[3] = {0, 0, 0};
@@ -381,6 +382,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     if (wf_bpp == 0) band_tile_rows = (size_t)P.tiles_y;
     band_tile_rows = std::min<size_t>(band_tile_rows, (size_t)P.tiles_y);
     const bool use_tree = tree_requested || band_tile_rows == 0;
+    s->last_schedule = use_tree ? 1 : 0;
     size_t lds = use_tree ? tree_kernel_lds_bytes(P, lds_scene) : wavefront_lds_bytes(P, lds_scene);
     if (lds > kMaxLdsBytes) return fail(P3D_ERR_LIMIT, "BVH depth / max_depth need more LDS than a CU has");
     if (lds > 64 * 1024 && !s->lds_prepared) {
@@ -484,6 +486,13 @@ int p3d_get_profile(p3d_scene* s, float* frame_ms, float* kernel_ms) {
     HIP_TRY(hipEventSynchronize(s->ev_prof[1]));
     HIP_TRY(hipEventElapsedTime(frame_ms, s->ev_prof[0], s->ev_prof[1]));
     HIP_TRY(hipEventElapsedTime(kernel_ms, s->ev_prof[2], s->ev_prof[3]));
+    return P3D_OK;
+}
+
+int p3d_last_schedule(p3d_scene* s, int32_t* schedule) {
+    if (!s || !schedule) return fail(P3D_ERR_ARG, "NULL argument");
+    if (s->last_schedule < 0) return fail(P3D_ERR_STATE, "no render yet");
+    *schedule = s->last_schedule;
     return P3D_OK;
 }
 
