@@ -101,8 +101,9 @@ typedef struct p3d_render_params {
 } p3d_render_params;
 
 #define P3D_FLAG_COUNTERS 1u     /* accumulate p3d_counters on the device (slower kernels)  */
-#define P3D_FLAG_WAVEFRONT 32u   /* force the wavefront schedule (default for scenes up to 2 MiB;
-                                    larger scenes default to the tree kernel)                     */
+#define P3D_FLAG_WAVEFRONT 32u   /* force the wavefront schedule (the default for scenes up to 2 MiB; for larger
+                                    ones the library times one frame of each schedule per configuration and
+                                    keeps the faster -- results are bit-identical either way)        */
 #define P3D_FLAG_PROFILE 16u     /* bracket the frame and its dominant kernel (the level-1 /
                                     tree launch) with HIP events for p3d_get_profile()           */
 #define P3D_FLAG_NO_PACKET 8u    /* per-lane BVH walk even for trees small enough for the

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Render a few frames of one scene (name of a golden .p3f, or N = primitives of the synthetic scaling
+scene) with one schedule: wavefront | tree | default.  For rocprofv3 runs.
+usage: render_frames.py SCENE SCHEDULE [FRAMES]"""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from conftest import scene_path
+import torch
+import u_4a_2s_p3d_raytracer_template2_amd as P
+from u_4a_2s_p3d_raytracer_template2_amd import synthetic as S, api
+arg, sched = sys.argv[1], sys.argv[2]
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+res = (1920, 1080)
+if arg.isdigit():
+    cam = P.HostScene(S.camera_p3f("/tmp/synth_camera.p3f", *res)).camera()
+    desc, keep = api.make_desc(*S.arrays(int(arg)))
+    ds = P.DeviceScene(desc, keepalive=keep)
+else:
+    hs = P.HostScene(scene_path(arg)); hs.set_resolution(*res)
+    ds, cam = P.DeviceScene.from_host(hs), hs.camera()
+buf = torch.zeros((res[1] + 16, res[0], 3), dtype=torch.uint8, device="cuda")
+kw = {"wavefront": dict(wavefront=True), "tree": dict(tree=True), "default": {}}[sched]
+for _ in range(n):
+    ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=4, **kw)
+ds.sync()
+print(ds.last_schedule())

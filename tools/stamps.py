@@ -9,16 +9,24 @@ import torch
 import u_4a_2s_p3d_raytracer_template2_amd as P
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 factor = 0
-hs = P.HostScene(scene_path("mount_low")); hs.set_resolution(1920, 1080); cam = hs.camera()
-ds = P.DeviceScene.from_host(hs)
-pass
+syn = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+kw = {}
+if syn:
+    from u_4a_2s_p3d_raytracer_template2_amd import synthetic as S, api
+    cam = P.HostScene(S.camera_p3f("/tmp/synth_camera.p3f", 1920, 1080)).camera()
+    desc, keep = api.make_desc(*S.arrays(syn))
+    ds = P.DeviceScene(desc, keepalive=keep)
+    kw = dict(wavefront=True)
+else:
+    hs = P.HostScene(scene_path("mount_low")); hs.set_resolution(1920, 1080); cam = hs.camera()
+    ds = P.DeviceScene.from_host(hs)
 buf = torch.zeros((1088, 1920, 3), dtype=torch.uint8, device="cuda")
 ntile = 120 * 68 + 64
 st = torch.zeros((ntile * 4, 8), dtype=torch.int64, device="cuda")
-for _ in range(3): ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=depth)
+for _ in range(3): ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=depth, **kw)
 ds.sync()
 ds.debug_set_stamps(st.data_ptr())
-ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=depth, profile=True)
+ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=depth, profile=True, **kw)
 print("profile (frame_ms, kernel_ms):", ds.profile())
 ds.debug_set_stamps(0)
 s = st.cpu().numpy()

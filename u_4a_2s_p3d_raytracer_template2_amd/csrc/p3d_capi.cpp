@@ -95,7 +95,7 @@ struct p3d_scene {
     DevBuf<LightRec> lights;
     size_t lds_scene_limit = 24 * 1024;  // blobs up to this size are rendered from an LDS copy
     int last_schedule = -1;
-    size_t tree_blob_limit = (size_t)2 << 20;   // scenes above this use the tree schedule by default
+    size_t tree_blob_limit = (size_t)2 << 20;   // scenes above this pick their schedule by measurement
     uint32_t packet_node_limit = 64;     // trees up to this many node pairs use the wave-wide walk
     float bg[3] = {0, 0, 0};
     uint32_t n_lights = 0, n_materials = 0;
@@ -109,6 +109,16 @@ struct p3d_scene {
     bool counters_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_prof[4] = {nullptr, nullptr, nullptr, nullptr};   // frame begin/end, dominant kernel begin/end
+    // Schedule choice for scenes above tree_blob_limit: measured, not guessed.  The first frame of a
+    // (resolution, depth, accel, spp, shard) configuration runs the wavefront schedule and the second
+    // the tree schedule, each bracketed by HIP events; later frames use the faster one.  Both produce
+    // identical bits, so the choice is invisible in the output.
+    struct SchedulePick {
+        int32_t key[7] = {0, 0, 0, -1, -1, 0, 0};
+        float ms[2] = {-1.0f, -1.0f};
+        int pending = -1;
+    } pick;
+    hipEvent_t ev_pick[2] = {nullptr, nullptr};
     bool profile_valid = false;
     bool timer_open = false;
     size_t lds_prepared = 0;
@@ -176,6 +186,7 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     if ((e = hipEventCreate(&s->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&s->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     for (auto& ev : s->ev_prof) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+    for (auto& ev : s->ev_pick) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
     {   // pack the per-lane-indexed arrays into one blob of 16-byte quads
         std::vector<uint32_t> blob;
         auto section = [&](const void* data, size_t bytes) {
@@ -226,6 +237,7 @@ int p3d_scene_destroy(p3d_scene* s) {
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (auto& ev : s->ev_prof) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : s->ev_pick) if (ev) (void)hipEventDestroy(ev);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
     return P3D_OK;
@@ -247,6 +259,7 @@ int p3d_set_tuning(p3d_scene* s, int32_t xcd_chunk, int32_t workspace_mib, int32
     if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
     if (xcd_chunk < 0 || xcd_chunk > (1 << 20)) return fail(P3D_ERR_ARG, "xcd_chunk must be >= 0");
     if (workspace_mib < 0) return fail(P3D_ERR_ARG, "workspace_mib must be >= 0");
+    s->pick.ms[0] = s->pick.ms[1] = -1.0f; s->pick.pending = -1;      // tuning changes what the schedules cost
     if (xcd_chunk) s->xcd_chunk = xcd_chunk;
     if (workspace_mib) s->workspace_budget = (size_t)workspace_mib << 20;
     if (waves_per_simd >= 0) {
@@ -369,12 +382,29 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     P.dbg_stamps = s->dbg_stamps;
     P.wf_min_width = lds_scene ? 64 : 8;
 
-    // Schedule: level-by-level wavefront unless the caller forces one, or the scene does not fit an
-    // XCD's L2 (every node visit of an incoherent ray is then a long dependent miss, ray cost varies
-    // by orders of magnitude, and a level launch lasts as long as its slowest ray: measured on the
-    // 100k-triangle dragon, tree 2.46 ms vs wavefront 3.41 ms; on the 2k-triangle mount_high 0.57 vs 0.38)
-    const bool tree_requested = (prm->flags & P3D_FLAG_TREE_KERNEL) ||
-                                (!(prm->flags & P3D_FLAG_WAVEFRONT) && (size_t)s->blob_quads * 16 > s->tree_blob_limit);
+    // Schedule: level-by-level wavefront unless the caller forces one.  Scenes that do not fit an
+    // XCD's L2 have no fixed winner -- 100k-triangle dragon: tree 2.4 ms, wavefront 3.4 ms (a level
+    // launch lasts as long as its slowest ray, four times per frame); 1e6 random primitives: tree
+    // 10.4 ms, wavefront 4.9 ms (every lane's tree is equally deep, so re-compacting rays per level
+    // wins) -- so for them the choice is measured: see SchedulePick.
+    bool tree_requested = (prm->flags & P3D_FLAG_TREE_KERNEL) != 0;
+    int measuring = -1;                 // schedule this frame is timed as, for the pick below
+    if (!(prm->flags & (P3D_FLAG_TREE_KERNEL | P3D_FLAG_WAVEFRONT)) && (size_t)s->blob_quads * 16 > s->tree_blob_limit) {
+        p3d_scene::SchedulePick& pk = s->pick;
+        const int32_t key[7] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world};
+        if (memcmp(key, pk.key, sizeof key) != 0) {
+            memcpy(pk.key, key, sizeof key);
+            pk.ms[0] = pk.ms[1] = -1.0f; pk.pending = -1;
+        }
+        if (pk.pending >= 0) {              // collect the measurement of the previous frame
+            HIP_TRY(hipEventSynchronize(s->ev_pick[1]));
+            HIP_TRY(hipEventElapsedTime(&pk.ms[pk.pending], s->ev_pick[0], s->ev_pick[1]));
+            pk.pending = -1;
+        }
+        if (pk.ms[0] < 0.0f) measuring = 0;
+        else if (pk.ms[1] < 0.0f) measuring = 1;
+        tree_requested = measuring >= 0 ? measuring == 1 : pk.ms[1] < pk.ms[0];
+    }
     // wavefront bands: worst-case queues for a band of tile rows must fit the workspace budget
     const size_t tile_row_px = (size_t)P.tiles_x * 64 * P.wg_waves;
     const size_t wf_bpp = wavefront_bytes_per_pixel(prm->max_depth) + (prm->spp > 0 ? 12 : 0);
@@ -413,6 +443,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     const bool profile = (prm->flags & P3D_FLAG_PROFILE) != 0;
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[0], s->stream));
     if (use_tree) {
+        if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));
         P.wf_tile_row0 = 0; P.wf_tile_rows = P.tiles_y;
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
         HIP_TRY(launch_tree(P, count, lds_scene, s->occupancy, s->stream));
@@ -426,6 +457,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         for (int l = 1; l <= D - 1; l++) HIP_TRY(s->wf_nodes[l].ensure((shard_px << (l - 1)) * kShards * sizeof(NodeRec)));
         HIP_TRY(s->wf_counts.ensure((size_t)2 * (kMaxDepth + 2) * kShards * sizeof(uint32_t)));
         if (prm->spp > 0) { HIP_TRY(s->wf_accum.ensure(npx * 12)); P.wf_accum = (float*)s->wf_accum.p; }
+        if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));   // after the (host-side) allocations
         // samples outermost: a pixel's clamped sample colours are summed in sample order
         for (int smp = 0; smp < P.wf_nsamples; smp++) {
             P.wf_sample = smp;
@@ -442,6 +474,12 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         }
     }
     if (profile) { HIP_TRY(hipEventRecord(s->ev_prof[1], s->stream)); s->profile_valid = true; }
+    if (measuring >= 0) {
+        HIP_TRY(hipEventRecord(s->ev_pick[1], s->stream));
+        // a frame forced onto the tree schedule by the workspace budget measures the tree schedule
+        s->pick.pending = use_tree ? 1 : 0;
+        if (use_tree && measuring == 0) s->pick.ms[0] = 3.0e38f;
+    }
     if (out->memory != 1) {
         // host planes hold res_y rows for a whole frame, p3d_local_rows() rows for a shard
         const size_t cpx = (world == 1 ? (size_t)cam->res_y : (size_t)P.local_rows) * cam->res_x;
