@@ -353,6 +353,8 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     const bool packet = !(prm->flags & P3D_FLAG_NO_PACKET) && s->stats.n_nodes <= s->packet_node_limit;
     P.n_planes = s->stats.n_planes; P.n_lights = s->n_lights; P.n_materials = s->n_materials;
     P.trav_stack_entries = std::max<uint32_t>(s->stats.max_depth + 1, 2);
+    // 8-byte slots for LDS-resident scenes, 6-byte slots for scenes read from HBM (p3d_traverse.h)
+    P.trav_stack_dwords = P.trav_stack_entries * (lds_scene ? 128u : 96u);
     memcpy(P.bg, s->bg, sizeof P.bg);
     memcpy(P.eye, cam->eye, sizeof P.eye); memcpy(P.u, cam->u, sizeof P.u);
     memcpy(P.v, cam->v, sizeof P.v); memcpy(P.n, cam->n, sizeof P.n);

@@ -67,7 +67,8 @@ struct LaunchParams {
     const PlaneRec*    planes;
     const PrimMeta*    plane_meta;
     const LightRec*    lights;
-    uint32_t n_planes, n_lights, n_materials, trav_stack_entries;
+    uint32_t n_planes, n_lights, n_materials;
+    uint32_t trav_stack_entries, trav_stack_dwords;   // walk-stack slots per lane; dwords of a wave's stack region
     float bg[3];
     // camera (RT/camera.h)
     float eye[3], u[3], v[3], n[3];

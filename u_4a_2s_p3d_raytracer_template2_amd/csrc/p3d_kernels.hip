@@ -193,10 +193,10 @@ template <> struct View<true> {
 template <bool LDS>
 __device__ __forceinline__ TravCtx wave_stack(const LaunchParams& P, uint32_t extra_dwords_per_wave, uint32_t** wave_base = nullptr) {
     const uint32_t wave = threadIdx.x >> 6;
-    uint32_t* base = p3d_lds + View<LDS>::scene_dwords(P) + wave * (P.trav_stack_entries * 128 + extra_dwords_per_wave);
+    uint32_t* base = p3d_lds + View<LDS>::scene_dwords(P) + wave * (P.trav_stack_dwords + extra_dwords_per_wave);
     if (wave_base) *wave_base = base;
     TravCtx tc;
-    tc.lane.base = reinterpret_cast<uint2*>(base) + (threadIdx.x & 63);
+    tc.lane.region = base; tc.lane.lane = threadIdx.x & 63; tc.lane.slots = P.trav_stack_entries;
     tc.wave.base = reinterpret_cast<int32_t*>(base);     // the two walks never run in the same launch
     return tc;
 }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kern
     const uint32_t frame_dwords = (uint32_t)(P.max_depth > 1 ? (P.max_depth - 1) : 1) * 12 * 64;
     uint32_t* wbase;
     const TravCtx st = wave_stack<LDS>(P, frame_dwords, &wbase);
-    Frames fr; fr.base = wbase + P.trav_stack_entries * 128 + lane;
+    Frames fr; fr.base = wbase + P.trav_stack_dwords + lane;
 
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
     V3 color = mk(0.0f, 0.0f, 0.0f);
@@ -497,11 +497,11 @@ __global__ void debug_intersect_kernel(uint32_t n, const uint32_t* type, const f
 static size_t scene_lds_bytes(const LaunchParams& P, bool lds) { return lds ? (size_t)P.blob_quads * 16 : 0; }
 size_t tree_kernel_lds_bytes(const LaunchParams& P, bool lds) {
     int frames = P.max_depth > 1 ? (P.max_depth - 1) : 1;
-    size_t wave_dwords = (size_t)P.trav_stack_entries * 128 + (size_t)frames * 12 * 64;
+    size_t wave_dwords = (size_t)P.trav_stack_dwords + (size_t)frames * 12 * 64;
     return scene_lds_bytes(P, lds) + wave_dwords * 4 * P.wg_waves;
 }
 size_t wavefront_lds_bytes(const LaunchParams& P, bool lds) {
-    return scene_lds_bytes(P, lds) + (size_t)P.trav_stack_entries * 512 * P.wg_waves;
+    return scene_lds_bytes(P, lds) + (size_t)P.trav_stack_dwords * 4 * P.wg_waves;
 }
 
 // counting builds always use the default register budget; timed builds pick OCC

@@ -71,14 +71,69 @@ template <class SV> __device__ __forceinline__ void sv_mat(const SV& sv, uint32_
     uint32_t q = sv.o.mats + m * 3u; a = sv.ld4(q); b = sv.ld4(q + 1); c = sv.ld4(q + 2);
 }
 
-// LDS traversal stack: 8-byte entries {node ref, entry distance}, [slot][lane]
+// A lane's traversal stack lives in its wave's LDS region, laid out [slot][lane].  An entry is a
+// node ref plus the ray's entry distance into that node (popped entries farther than the best hit
+// are skipped without touching memory).  Two layouts behind one interface:
+//  WideStack  8-byte entries {ref, t as f32}: one ds_write_b64 / ds_read_b64.  Scenes rendered from
+//             an LDS copy -- their trees are a few levels deep and the kernels are issue-bound.
+//  SlimStack  6-byte entries: refs in one [slot][lane] plane, t truncated to its upper 16 bits in a
+//             second one.  Scenes read from HBM -- a depth-25 stack is 12.8 KB per wave wide, 9.6 KB
+//             slim, which is the difference between 12 and 16 resident waves per CU for kernels that
+//             wait on memory most of the time.  Truncation moves a positive t towards zero and best.t
+//             is never negative, so a stored distance never exceeds the true one by more than it may:
+//             the skip test stays conservative (it only ever visits a node it could have skipped).
 struct TravStack {
-    uint2* base;         // points at this lane's slot-0 entry; slot stride = 64 entries
-    __device__ __forceinline__ void push(int sp, int32_t node, float t) {
-        base[sp * 64] = make_uint2((uint32_t)node, __float_as_uint(t));
-    }
-    __device__ __forceinline__ uint2 at(int sp) const { return base[sp * 64]; }
+    uint32_t* region;    // this wave's stack region
+    uint32_t lane, slots;
 };
+constexpr uint32_t kWideStackDwords = 128, kSlimStackDwords = 96;    // per slot per wave
+
+struct WideStack {
+    uint2* base; int sp;
+    __device__ __forceinline__ explicit WideStack(const TravStack& r)
+        : base(reinterpret_cast<uint2*>(r.region) + r.lane), sp(0) {}
+    __device__ __forceinline__ void push(int32_t node, float t) {
+        base[sp * 64] = make_uint2((uint32_t)node, __float_as_uint(t)); sp++;
+    }
+    // next entry not farther than tmax, or false when the stack is empty
+    __device__ __forceinline__ bool pop(float tmax, int32_t& node) {
+        while (sp > 0) {
+            sp--;
+            const uint2 e = base[sp * 64];
+            if (__uint_as_float(e.y) <= tmax) { node = (int32_t)e.x; return true; }
+        }
+        return false;
+    }
+    __device__ __forceinline__ bool pop(int32_t& node) {
+        if (sp == 0) return false;
+        sp--; node = (int32_t)base[sp * 64].x;
+        return true;
+    }
+};
+struct SlimStack {
+    uint32_t* refs; uint16_t* dist; int sp;
+    __device__ __forceinline__ explicit SlimStack(const TravStack& r)
+        : refs(r.region + r.lane), dist(reinterpret_cast<uint16_t*>(r.region + r.slots * 64) + r.lane), sp(0) {}
+    __device__ __forceinline__ void push(int32_t node, float t) {
+        refs[sp * 64] = (uint32_t)node; dist[sp * 64] = (uint16_t)(__float_as_uint(t) >> 16); sp++;
+    }
+    __device__ __forceinline__ bool pop(float tmax, int32_t& node) {
+        while (sp > 0) {
+            sp--;
+            const float t = __uint_as_float((uint32_t)dist[sp * 64] << 16);
+            if (t <= tmax) { node = (int32_t)refs[sp * 64]; return true; }
+        }
+        return false;
+    }
+    __device__ __forceinline__ bool pop(int32_t& node) {
+        if (sp == 0) return false;
+        sp--; node = (int32_t)refs[sp * 64];
+        return true;
+    }
+};
+template <class SV> struct StackOf;
+template <> struct StackOf<LdsScene> { typedef WideStack type; };
+template <> struct StackOf<GlobalScene> { typedef SlimStack type; };
 
 struct SlabRay { float ox, oy, oz, ix, iy, iz; };
 
@@ -140,7 +195,7 @@ __device__ __forceinline__ void leaf_closest(const LaunchParams& P, const SV& sv
 
 // closest hit over planes (unbounded, outside the BVH) + BVH
 template <bool COUNT, class SV>
-__device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const SV& sv, const Ray& r, TravStack st, Ctr& ctr) {
+__device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const SV& sv, const Ray& r, TravStack region, Ctr& ctr) {
     Hit best; best.t = 3.402823466e+38f; best.ref = 0xFFFFFFFFu; best.sid = 0xFFFFFFFFu; best.mat = 0;
     if (COUNT) ctr.closest++;
     for (uint32_t i = 0; i < P.n_planes; i++) {
@@ -155,7 +210,7 @@ __device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const SV& sv, 
         }
     }
     SlabRay s = make_slab(r);
-    int sp = 0;
+    typename StackOf<SV>::type st(region);
     int32_t cur = 0;
     while (cur != P3D_DONE) {
         while (cur >= 0) {
@@ -169,27 +224,15 @@ __device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const SV& sv, 
                 bool swap = tn1 < tn0;
                 int32_t nearc = swap ? q3.y : q3.x, farc = swap ? q3.x : q3.y;
                 float fart = swap ? tn0 : tn1;
-                st.push(sp, farc, fart); sp++;
+                st.push(farc, fart);
                 cur = nearc;
             } else if (h0) cur = q3.x;
             else if (h1) cur = q3.y;
-            else {
-                cur = P3D_DONE;
-                while (sp > 0) {
-                    sp--;
-                    uint2 e = st.at(sp);
-                    if (__uint_as_float(e.y) <= best.t) { cur = (int32_t)e.x; break; }
-                }
-            }
+            else if (!st.pop(best.t, cur)) cur = P3D_DONE;
         }
         if (cur != P3D_DONE) {
             leaf_closest<COUNT>(P, sv, r, cur, best, ctr);
-            cur = P3D_DONE;
-            while (sp > 0) {
-                sp--;
-                uint2 e = st.at(sp);
-                if (__uint_as_float(e.y) <= best.t) { cur = (int32_t)e.x; break; }
-            }
+            if (!st.pop(best.t, cur)) cur = P3D_DONE;
         }
     }
     return best;
@@ -230,7 +273,7 @@ __device__ __forceinline__ bool leaf_any(const LaunchParams& P, const SV& sv, co
 
 template <bool COUNT, class SV>
 __device__ __forceinline__ bool any_hit(const LaunchParams& P, const SV& sv, const Ray& r, bool bounded, float tmax,
-                                        TravStack st, Ctr& ctr) {
+                                        TravStack region, Ctr& ctr) {
     if (COUNT) ctr.shadow++;
     if (P.n_planes) {
         // planes: always candidates without an accelerator; behind the default [-1,1]^3 box
@@ -247,7 +290,7 @@ __device__ __forceinline__ bool any_hit(const LaunchParams& P, const SV& sv, con
     }
     SlabRay s = make_slab(r);
     float tlimit = bounded ? tmax : 3.402823466e+38f;
-    int sp = 0;
+    typename StackOf<SV>::type st(region);
     int32_t cur = 0;
     while (cur != P3D_DONE) {
         while (cur >= 0) {
@@ -259,17 +302,15 @@ __device__ __forceinline__ bool any_hit(const LaunchParams& P, const SV& sv, con
             if (COUNT) ctr.box += 2;
             if (h0 && h1) {
                 bool swap = tn1 < tn0;
-                st.push(sp, swap ? q3.x : q3.y, 0.0f); sp++;
+                st.push(swap ? q3.x : q3.y, 0.0f);
                 cur = swap ? q3.y : q3.x;
             } else if (h0) cur = q3.x;
             else if (h1) cur = q3.y;
-            else if (sp > 0) { sp--; cur = (int32_t)st.at(sp).x; }
-            else cur = P3D_DONE;
+            else if (!st.pop(cur)) cur = P3D_DONE;
         }
         if (cur != P3D_DONE) {
             if (leaf_any<COUNT>(P, sv, r, cur, bounded, tmax, ctr)) return true;
-            if (sp > 0) { sp--; cur = (int32_t)st.at(sp).x; }
-            else cur = P3D_DONE;
+            if (!st.pop(cur)) cur = P3D_DONE;
         }
     }
     return false;
