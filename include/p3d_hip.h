@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define P3D_ABI_VERSION 1
+#define P3D_ABI_VERSION 2
 
 typedef enum p3d_status {
     P3D_OK = 0,
@@ -98,7 +98,22 @@ typedef struct p3d_render_params {
     int32_t  row_block;      /* rows per block, multiple of 16; 0 = default (16)         */
     int32_t  rank, world;
     uint32_t flags;          /* P3D_FLAG_*                                              */
+    uint32_t features;       /* P3D_FEATURE_*: the reference's distribution-ray-tracing switches */
+    uint32_t seed;           /* seed of the device random streams those features draw from       */
 } p3d_render_params;
+
+/* SOFT_SHADOW / FUZZY_REFLECTION of RT/main.cpp:41,43 (compile-time false there).
+ * SOFT_SHADOW: every light becomes the reference's 0.5 x 0.5 area light -- with spp == 0 its
+ * deterministic 4x4 grid of sub-lights of colour/16 (RT/main.cpp:601-618, bit-faithful), with
+ * spp > 0 one jittered position per pixel sample in that sample's stratum (RT/main.cpp:620-624).
+ * FUZZY_REFLECTION: mirror directions perturbed inside a sphere of radius 0.3 (RT/main.cpp:651-660).
+ * The jitter and the fuzz draw from counter-based device random streams keyed by (seed, pixel, sample,
+ * tree node): the reference's serial rand() stream is not reproducible in parallel, so these two are
+ * statistically, not bitwise, equal to it. They need the wavefront schedule (P3D_FLAG_TREE_KERNEL is
+ * rejected). DEPTH_OF_FIELD is implied by spp > 0 as in the reference (RT/main.cpp:943-944);
+ * MOTION_BLUR only stamps rays with a time no object reads, so it has no switch. */
+#define P3D_FEATURE_SOFT_SHADOW 1u
+#define P3D_FEATURE_FUZZY_REFLECTION 2u
 
 #define P3D_FLAG_COUNTERS 1u     /* accumulate p3d_counters on the device (slower kernels)  */
 #define P3D_FLAG_WAVEFRONT 32u   /* force the wavefront schedule (the default for scenes up to 2 MiB; for larger

@@ -18,7 +18,7 @@ SPHERE, TRIANGLE, BOX, PLANE = 0, 1, 2, 3
 class Params(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("accel", C.c_int32), ("spp", C.c_int32),
                 ("seed", C.c_uint32), ("threads", C.c_int32), ("break_fixed", C.c_int32),
-                ("y0", C.c_int32), ("y1", C.c_int32)]
+                ("y0", C.c_int32), ("y1", C.c_int32), ("soft_shadow", C.c_int32), ("fuzzy_reflection", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -175,13 +175,13 @@ class Scene:
         return o, d
 
     def render(self, max_depth=4, accel=-1, spp=-1, seed=12345, threads=1, break_fixed=0,
-               want_f32=True, want_hit=True, y0=0, y1=0):
+               want_f32=True, want_hit=True, y0=0, y1=0, soft_shadow=False, fuzzy_reflection=False):
         """Returns dict(rgb8 [H,W,3] u8 bottom row first, rgb32f, hit_id, counters)."""
         W, H = self.res_x, self.res_y
         rgb8 = np.zeros((H, W, 3), np.uint8)
         f32 = np.zeros((H, W, 3), np.float32) if want_f32 else None
         hid = np.full((H, W), -2, np.int32) if want_hit else None
-        prm = Params(max_depth, accel, spp, seed, threads, break_fixed, y0, y1)
+        prm = Params(max_depth, accel, spp, seed, threads, break_fixed, y0, y1, int(soft_shadow), int(fuzzy_reflection))
         ctr = Counters()
         rc = lib().p3o_render(self.h, C.byref(prm), rgb8.ctypes.data,
                               f32.ctypes.data if want_f32 else None,

@@ -625,6 +625,14 @@ struct p3o_scene {
 namespace {
 
 // ---- tracer state: one per thread (the reference has one, globally)
+V3 rnd_unit_sphere() {                                                   // RT/maths.h:98-104
+    V3 p;
+    do {
+        p = V3(rand_float(), rand_float(), rand_float()) * 2 - V3(1.0, 1.0, 1.0);
+    } while (dot(p, p) >= 1.0);
+    return p;
+}
+
 struct Tracer {
     p3o_scene* sc;
     std::vector<Prim>* prims;     // thread-private copy when threads>1 (box normal side effects)
@@ -634,6 +642,10 @@ struct Tracer {
     int max_depth;
     bool break_fixed;
     int32_t last_primary_hit;
+    // distribution-ray-tracing switches (compile-time false in the reference, RT/main.cpp:40-45)
+    bool soft_shadow = false, fuzzy_reflection = false;
+    int spp = 0;                                   // globalSamplesPerPixel; ANTI_ALIASING == spp > 0 (RT/main.cpp:943)
+    int offset_for_shadowx = 0, offset_for_shadowy = 0;                  // RT/main.cpp:101,779-780
 
     Prim& obj(int i) { g_ctr.get_object++; return (*prims)[i]; }         // RT/scene.cpp:307-312
 
@@ -703,8 +715,36 @@ struct Tracer {
         V3 V = ray.d * (-1);
 
         for (size_t i = 0; i < sc->lights.size(); ++i) {
-            V3 L = sc->lights[i].pos - hit_point;
-            processLight(L, sc->lights[i].col, color, M, ray, precise, normal);
+            const auto& light = sc->lights[i];
+            if (soft_shadow) {                                           // RT/main.cpp:598-625
+                float shadow = 0.5f;
+                if (spp == 0) {
+                    float distance = shadow / 4;
+                    float cur_x = light.pos.x - distance * shadow * 4;
+                    float cur_y = light.pos.y - distance * shadow * 4;
+                    Col avg_col = light.col / (4 * 4);
+                    for (int a = 0; a < 4; a++) {
+                        for (int b = 0; b < 4; b++) {
+                            V3 position(cur_x, cur_y, light.pos.z);
+                            V3 L = position - hit_point;
+                            processLight(L, avg_col, color, M, ray, precise, normal);
+                            cur_x += distance;
+                        }
+                        cur_y += distance;
+                        cur_x = light.pos.x - distance * shadow * 4;
+                    }
+                } else {
+                    // same expression shape as the reference (g++ evaluates the constructor
+                    // arguments right to left, like sampleUnitDisk below)
+                    V3 position(light.pos.x + shadow * ((offset_for_shadowx + rand_float()) / spp),
+                                light.pos.y + shadow * ((offset_for_shadowy + rand_float()) / spp), light.pos.z);
+                    V3 L = position - hit_point;
+                    processLight(L, light.col, color, M, ray, precise, normal);
+                }
+            } else {
+                V3 L = light.pos - hit_point;
+                processLight(L, light.col, color, M, ray, precise, normal);
+            }
         }
         if (depth >= max_depth) return clampc(color);
 
@@ -714,7 +754,15 @@ struct Tracer {
 
         if (M.refl > 0 && depth < max_depth) {
             V3 rdir = ray.d - (normal * dot(ray.d, normal) * 2);
-            normalize(rdir);
+            if (fuzzy_reflection) {                                      // RT/main.cpp:651-660
+                V3 sphere_center = rdir + precise;
+                V3 sphere_offset = sphere_center + rnd_unit_sphere() * 0.3f;
+                V3 fuzzy = sphere_offset - precise;
+                normalize(fuzzy);
+                if (dot(fuzzy, normal) > 0) rdir = fuzzy;        // otherwise the un-normalised mirror direction
+            } else {
+                normalize(rdir);
+            }
             RayO rr; rr.o = precise; rr.d = rdir;
             g_ctr.rays++;
             reflection_color = rayTracing(rr, depth + 1, ior_1, false);
@@ -784,6 +832,7 @@ void render_rows(Tracer& T, int y0, int y1, unsigned spp, uint8_t* rgb8, float* 
             } else {
                 for (unsigned i = 0; i < spp; i++)
                     for (unsigned j = 0; j < spp; j++) {
+                        T.offset_for_shadowx = (int)i; T.offset_for_shadowy = (int)j;
                         pixel.x = x + (i + rand_float()) / spp;
                         pixel.y = y + (j + rand_float()) / spp;
                         V3 lens = sampleUnitDisk() * cam.aperture;
@@ -970,13 +1019,14 @@ int p3o_render(p3o_scene* sc, const p3o_params* prm, uint8_t* rgb8, float* rgb32
     int y1 = prm->y1 > 0 ? std::min(prm->y1, H) : H;
     ensure_accel(sc, accel);
     int threads = prm->threads > 1 ? prm->threads : 1;
-    if (spp != 0) threads = 1;            // libc rand() stream is consumed in pixel order
+    if (spp != 0 || prm->fuzzy_reflection) threads = 1;   // libc rand() stream is consumed in pixel order
     p3o_counters total; memset(&total, 0, sizeof total);
     if (threads == 1) {
         memset(&g_ctr, 0, sizeof g_ctr);
         if (spp != 0) srand(prm->seed);                                   // RT/main.cpp:747
         Tracer T; T.sc = sc; T.prims = &sc->prims; T.bvh = &sc->bvh; T.grid = &sc->grid;
         T.accel = accel; T.max_depth = prm->max_depth; T.break_fixed = prm->break_fixed != 0;
+        T.soft_shadow = prm->soft_shadow != 0; T.fuzzy_reflection = prm->fuzzy_reflection != 0; T.spp = (int)spp;
         T.last_primary_hit = -1;
         sc->bvh.hit_stack.clear();
         render_rows(T, y0, y1, spp, rgb8, rgb32f, hit_id);
@@ -993,6 +1043,7 @@ int p3o_render(p3o_scene* sc, const p3o_params* prm, uint8_t* rgb8, float* rgb32
                 RefGrid grid = sc->grid; grid.prims = &priv;
                 Tracer T; T.sc = sc; T.prims = &priv; T.bvh = &bvh; T.grid = &grid;
                 T.accel = accel; T.max_depth = prm->max_depth; T.break_fixed = prm->break_fixed != 0;
+        T.soft_shadow = prm->soft_shadow != 0; T.fuzzy_reflection = prm->fuzzy_reflection != 0; T.spp = (int)spp;
                 T.last_primary_hit = -1;
                 const int blk = 8;
                 for (int b = y0 / blk; b * blk < y1; b++) {

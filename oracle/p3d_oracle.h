@@ -39,6 +39,9 @@ typedef struct p3o_params {
     int32_t threads;      /* 1 = serial, exactly the reference's order (the oracle proper)       */
     int32_t break_fixed;  /* 1 = use the BVH closest hit, no fall-through (SURVEY Q1 removed)    */
     int32_t y0, y1;       /* row range [y0,y1); y1<=0 means all rows                             */
+    int32_t soft_shadow;  /* SOFT_SHADOW of RT/main.cpp:41: 4x4 area-light grid when spp == 0, one
+                             jittered light sample per pixel sample otherwise (RT/main.cpp:598-625)  */
+    int32_t fuzzy_reflection; /* FUZZY_REFLECTION of RT/main.cpp:43 (RT/main.cpp:651-660)            */
 } p3o_params;
 
 typedef struct p3o_counters {

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libp3d_hip.so does not export %s" % name
     assert sorted(api.C_ABI_SYMBOLS) == declared
-    assert L.p3d_abi_version() == 1
+    assert L.p3d_abi_version() == 2
     pt_header = open(os.path.join(REPO, "include", "p3d_pathtracer.h")).read()
     pt_declared = sorted(set(re.findall(r"\b(p3d_pt_[a-z_]+)\s*\(", pt_header)))
     assert pt_declared == sorted(api.PT_C_ABI_SYMBOLS)

@@ -26,7 +26,7 @@ static int save_ppm(const char* path, const std::vector<uint8_t>& img, int w, in
 int main(int argc, char** argv) {
     if (argc < 2) {
         fprintf(stderr, "usage: %s scene.p3f [--res W H] [--accel A] [--depth D] [--spp N] [--seed S] "
-                        "[--device K] [--out file.ppm] [--counters]\n", argv[0]);
+                        "[--device K] [--out file.ppm] [--counters] [--soft-shadow] [--fuzzy-reflection]\n", argv[0]);
         return 2;
     }
     RenderOptions opt;
@@ -43,6 +43,8 @@ int main(int argc, char** argv) {
         else if (a == "--device") { need(1); opt.device = atoi(argv[++i]); }
         else if (a == "--out") { need(1); out = argv[++i]; }
         else if (a == "--counters") opt.counters = true;
+        else if (a == "--soft-shadow") opt.SOFT_SHADOW = true;
+        else if (a == "--fuzzy-reflection") opt.FUZZY_REFLECTION = true;
         else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     Scene scene;

@@ -313,6 +313,8 @@ int renderScene(const Scene& scene, const RenderOptions& opt, bool want_colors, 
     prm.spp = opt.spp < 0 ? (int)scene.GetSamplesPerPixel() : opt.spp;
     prm.world = 1; prm.rank = 0; prm.row_block = 16;
     prm.flags = opt.counters ? P3D_FLAG_COUNTERS : 0;
+    prm.features = (opt.SOFT_SHADOW ? P3D_FEATURE_SOFT_SHADOW : 0u) | (opt.FUZZY_REFLECTION ? P3D_FEATURE_FUZZY_REFLECTION : 0u);
+    prm.seed = opt.seed;
     std::vector<float> samples;
     if (prm.spp > 0) {
         samples.resize((size_t)cam.res_x * cam.res_y * prm.spp * prm.spp * 4);

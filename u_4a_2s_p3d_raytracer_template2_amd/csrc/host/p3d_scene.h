@@ -213,6 +213,10 @@ struct RenderOptions {
     unsigned seed = 12345;    // replaces time(NULL)
     int device = 0;
     bool counters = false;
+    // the reference's distribution-ray-tracing globals (RT/main.cpp:41,43); ANTI_ALIASING and
+    // DEPTH_OF_FIELD follow spp > 0 as in RT/main.cpp:943-944
+    bool SOFT_SHADOW = false;
+    bool FUZZY_REFLECTION = false;
 };
 struct RenderResult {
     std::vector<uint8_t> img_Data;   // RGB8, bottom row first (RT/main.cpp:76)

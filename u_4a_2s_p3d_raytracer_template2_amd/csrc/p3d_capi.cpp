@@ -93,6 +93,8 @@ struct p3d_scene {
     DevBuf<PlaneRec> planes;
     DevBuf<PrimMeta> plane_meta;
     DevBuf<LightRec> lights;
+    DevBuf<LightRec> soft_lights;          // 16 sub-lights per light, built on first use (SOFT_SHADOW, spp == 0)
+    std::vector<LightRec> host_lights;
     size_t lds_scene_limit = 24 * 1024;  // blobs up to this size are rendered from an LDS copy
     int last_schedule = -1;
     size_t tree_blob_limit = (size_t)2 << 20;   // scenes above this pick their schedule by measurement
@@ -104,6 +106,7 @@ struct p3d_scene {
     RawBuf ray_tab; int tab_res_x = 0, tab_res_y = 0;   // cached per-column / per-row ray factors
     // wavefront workspace: ray queues (levels 2..D), parked nodes (levels 1..D-1), counters
     RawBuf wf_rays[kMaxDepth + 2], wf_nodes[kMaxDepth + 2], wf_counts, wf_accum;
+    RawBuf wf_rng[kMaxDepth + 2];            // random-stream keys of the queued rays (stochastic features)
     size_t workspace_budget = (size_t)8 << 30;
     DeviceCounters* d_counters = nullptr;
     bool counters_valid = false;
@@ -210,6 +213,7 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     if ((e = s->planes.upload(planes)) != hipSuccess) return bail(e, "upload planes");
     if ((e = s->plane_meta.upload(plane_meta)) != hipSuccess) return bail(e, "upload plane meta");
     if ((e = s->lights.upload(lights)) != hipSuccess) return bail(e, "upload lights");
+    s->host_lights = lights;
     if ((e = hipMalloc((void**)&s->d_counters, sizeof(DeviceCounters))) != hipSuccess) return bail(e, "alloc counters");
     if ((e = hipMemset(s->d_counters, 0, sizeof(DeviceCounters))) != hipSuccess) return bail(e, "clear counters");
     memcpy(s->bg, d->background, sizeof s->bg);
@@ -228,11 +232,12 @@ int p3d_scene_destroy(p3d_scene* s) {
     if (!s) return P3D_OK;
     (void)hipSetDevice(s->device);
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
-    s->blob.release(); s->planes.release(); s->plane_meta.release(); s->lights.release();
+    s->blob.release(); s->planes.release(); s->plane_meta.release(); s->lights.release(); s->soft_lights.release();
     s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release(); s->ray_tab.release();
     for (auto& b : s->wf_rays) b.release();
     for (auto& b : s->wf_nodes) b.release();
     s->wf_counts.release(); s->wf_accum.release();
+    for (auto& b : s->wf_rng) b.release();
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -299,6 +304,8 @@ int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, bool lds, bool 
     P.wf_level = 1;
     P.wf_rays_in = nullptr; P.wf_count_in = nullptr; P.wf_cap_in = 0;
     P.wf_rays_out = rays(2); P.wf_count_out = qcount(2); P.wf_cap_out = cap(2);
+    auto rng = [&](int l) { return (P.features && l >= 2 && l <= D) ? (uint32_t*)s->wf_rng[l].p : nullptr; };
+    P.wf_rng_in = nullptr; P.wf_rng_out = rng(2);
     P.wf_nodes_parent = nullptr; P.wf_ncap_parent = 0;
     P.wf_nodes_self = nodes(1); P.wf_ncount_self = ncount(1); P.wf_ncap_self = cap(1);
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
@@ -308,6 +315,7 @@ int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, bool lds, bool 
         P.wf_level = l;
         P.wf_rays_in = rays(l); P.wf_count_in = qcount(l); P.wf_cap_in = cap(l);
         P.wf_rays_out = rays(l + 1); P.wf_count_out = qcount(l + 1); P.wf_cap_out = cap(l + 1);
+        P.wf_rng_in = rng(l); P.wf_rng_out = rng(l + 1);
         P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = cap(l - 1);
         P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
         size_t total = (size_t)cap(l) * kShards;
@@ -389,9 +397,43 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     // launch lasts as long as its slowest ray, four times per frame); 1e6 random primitives: tree
     // 10.4 ms, wavefront 4.9 ms (every lane's tree is equally deep, so re-compacting rays per level
     // wins) -- so for them the choice is measured: see SchedulePick.
+    // distribution-ray-tracing switches (RT/main.cpp:40-45)
+    if (prm->features & ~(P3D_FEATURE_SOFT_SHADOW | P3D_FEATURE_FUZZY_REFLECTION)) return fail(P3D_ERR_ARG, "unknown feature bit");
+    if ((prm->features & P3D_FEATURE_SOFT_SHADOW) && prm->spp == 0 && s->n_lights) {
+        // the 4x4 grid of RT/main.cpp:601-618 as 16 sub-lights per light, in the reference's loop order
+        // and with its float arithmetic (cur_x / cur_y advance by repeated addition)
+        if (!s->soft_lights.p) {
+            std::vector<LightRec> sub;
+            for (const LightRec& li : s->host_lights) {
+                const float shadow = 0.5f, distance = shadow / 4;
+                float cur_x = li.pos[0] - distance * shadow * 4;
+                float cur_y = li.pos[1] - distance * shadow * 4;
+                for (int a = 0; a < 4; a++) {
+                    for (int b = 0; b < 4; b++) {
+                        LightRec q = li;
+                        q.pos[0] = cur_x; q.pos[1] = cur_y;
+                        for (int c = 0; c < 3; c++) q.col[c] = li.col[c] / (4 * 4);
+                        sub.push_back(q);
+                        cur_x += distance;
+                    }
+                    cur_y += distance;
+                    cur_x = li.pos[0] - distance * shadow * 4;
+                }
+            }
+            HIP_TRY(s->soft_lights.upload(sub));
+        }
+        P.lights = s->soft_lights.p; P.n_lights = s->n_lights * 16;
+    }
+    if ((prm->features & P3D_FEATURE_SOFT_SHADOW) && prm->spp > 0) P.features |= kFeatSoftJitter;
+    if (prm->features & P3D_FEATURE_FUZZY_REFLECTION) P.features |= kFeatFuzzy;
+    P.seed = prm->seed;
+    const bool stochastic = P.features != 0;
+    if (stochastic && (prm->flags & P3D_FLAG_TREE_KERNEL))
+        return fail(P3D_ERR_ARG, "features with random draws need the wavefront schedule");
     bool tree_requested = (prm->flags & P3D_FLAG_TREE_KERNEL) != 0;
     int measuring = -1;                 // schedule this frame is timed as, for the pick below
-    if (!(prm->flags & (P3D_FLAG_TREE_KERNEL | P3D_FLAG_WAVEFRONT)) && (size_t)s->blob_quads * 16 > s->tree_blob_limit) {
+    if (!stochastic && !(prm->flags & (P3D_FLAG_TREE_KERNEL | P3D_FLAG_WAVEFRONT)) &&
+        (size_t)s->blob_quads * 16 > s->tree_blob_limit) {
         p3d_scene::SchedulePick& pk = s->pick;
         const int32_t key[7] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world};
         if (memcmp(key, pk.key, sizeof key) != 0) {
@@ -409,11 +451,13 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     }
     // wavefront bands: worst-case queues for a band of tile rows must fit the workspace budget
     const size_t tile_row_px = (size_t)P.tiles_x * 64 * P.wg_waves;
-    const size_t wf_bpp = wavefront_bytes_per_pixel(prm->max_depth) + (prm->spp > 0 ? 12 : 0);
+    size_t wf_bpp = wavefront_bytes_per_pixel(prm->max_depth) + (prm->spp > 0 ? 12 : 0);
+    if (stochastic) for (int l = 2; l <= prm->max_depth; l++) wf_bpp += ((size_t)1 << (l - 1)) * sizeof(uint32_t);
     size_t band_tile_rows = wf_bpp ? s->workspace_budget / (wf_bpp * tile_row_px) : (size_t)P.tiles_y;
     if (wf_bpp == 0) band_tile_rows = (size_t)P.tiles_y;
     band_tile_rows = std::min<size_t>(band_tile_rows, (size_t)P.tiles_y);
     const bool use_tree = tree_requested || band_tile_rows == 0;
+    if (use_tree && stochastic) return fail(P3D_ERR_LIMIT, "workspace budget too small for the wavefront schedule the features need");
     s->last_schedule = use_tree ? 1 : 0;
     size_t lds = use_tree ? tree_kernel_lds_bytes(P, lds_scene) : wavefront_lds_bytes(P, lds_scene);
     if (lds > kMaxLdsBytes) return fail(P3D_ERR_LIMIT, "BVH depth / max_depth need more LDS than a CU has");
@@ -458,6 +502,8 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         for (int l = 2; l <= D; l++) HIP_TRY(s->wf_rays[l].ensure((shard_px << (l - 1)) * kShards * sizeof(RayRec)));
         for (int l = 1; l <= D - 1; l++) HIP_TRY(s->wf_nodes[l].ensure((shard_px << (l - 1)) * kShards * sizeof(NodeRec)));
         HIP_TRY(s->wf_counts.ensure((size_t)2 * (kMaxDepth + 2) * kShards * sizeof(uint32_t)));
+        if (stochastic)
+            for (int l = 2; l <= D; l++) HIP_TRY(s->wf_rng[l].ensure((shard_px << (l - 1)) * kShards * sizeof(uint32_t)));
         if (prm->spp > 0) { HIP_TRY(s->wf_accum.ensure(npx * 12)); P.wf_accum = (float*)s->wf_accum.p; }
         if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));   // after the (host-side) allocations
         // samples outermost: a pixel's clamped sample colours are summed in sample order

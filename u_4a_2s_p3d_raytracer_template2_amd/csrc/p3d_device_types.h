@@ -55,6 +55,8 @@ struct DeviceCounters {
         aabox_tests, plane_tests, pixels;
 };
 
+constexpr uint32_t kFeatSoftJitter = 1u, kFeatFuzzy = 2u;                  // LaunchParams::features
+
 // Everything a render launch needs, passed by value (lands in SGPRs / kernarg segment).
 struct LaunchParams {
     // scene: one blob of 16-byte quads holding every per-lane-indexed array (nodes, leaf refs,
@@ -102,6 +104,10 @@ struct LaunchParams {
     NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
     float* wf_accum;                                              // [local px][3] running sample sum
     int32_t wf_min_width;            // fewest lanes a deeper-level wave may use (64 = never narrow)
+    // distribution-ray-tracing features with random draws (p3d_shade.h): feature bits, frame seed, and
+    // the random-stream key of every queued ray ([shard][cap] like the ray queues; nullptr when off)
+    uint32_t features, seed;
+    const uint32_t* wf_rng_in; uint32_t* wf_rng_out;
     unsigned long long* dbg_stamps;   // diagnostic: per (tile, wave) 8 x u64 timestamps, or nullptr
 };
 

@@ -104,6 +104,7 @@ struct Shard {
     const RayRec* rays_in; uint32_t count_in;
     RayRec* rays_out; uint32_t* count_out;
     NodeRec* nodes_parent; NodeRec* nodes_self; uint32_t* ncount_self;
+    const uint32_t* rng_in; uint32_t* rng_out;     // random-stream keys of the queued rays, or nullptr
 };
 __device__ __forceinline__ Shard shard_of(const LaunchParams& P, uint32_t s) {
     Shard h;
@@ -114,6 +115,8 @@ __device__ __forceinline__ Shard shard_of(const LaunchParams& P, uint32_t s) {
     h.nodes_parent = P.wf_nodes_parent ? P.wf_nodes_parent + (size_t)s * P.wf_ncap_parent : nullptr;
     h.nodes_self = P.wf_nodes_self ? P.wf_nodes_self + (size_t)s * P.wf_ncap_self : nullptr;
     h.ncount_self = P.wf_ncount_self + s;
+    h.rng_in = P.wf_rng_in ? P.wf_rng_in + (size_t)s * P.wf_cap_in : nullptr;
+    h.rng_out = P.wf_rng_out ? P.wf_rng_out + (size_t)s * P.wf_cap_out : nullptr;
     return h;
 }
 
@@ -152,14 +155,18 @@ __device__ __forceinline__ void emit(const LaunchParams& P, const Shard& sh, int
     nd[1] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(o.mat));
     nd[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(link));
     if (o.has_refl) {                                           // reflection child keeps ior_1
-        float4* rq = reinterpret_cast<float4*>(sh.rays_out + ray_base + lane_rank(m_refl));
+        const uint32_t slot = ray_base + lane_rank(m_refl);
+        float4* rq = reinterpret_cast<float4*>(sh.rays_out + slot);
         rq[0] = make_float4(o.refl.o.x, o.refl.o.y, o.refl.o.z, ior_1);
         rq[1] = make_float4(o.refl.d.x, o.refl.d.y, o.refl.d.z, __uint_as_float(my_node));
+        if (sh.rng_out) sh.rng_out[slot] = o.rng_refl;
     }
     if (o.has_refr) {
-        float4* rq = reinterpret_cast<float4*>(sh.rays_out + ray_base + n_refl + lane_rank(m_refr));
+        const uint32_t slot = ray_base + n_refl + lane_rank(m_refr);
+        float4* rq = reinterpret_cast<float4*>(sh.rays_out + slot);
         rq[0] = make_float4(o.refr.o.x, o.refr.o.y, o.refr.o.z, o.newIor);
         rq[1] = make_float4(o.refr.d.x, o.refr.d.y, o.refr.d.z, __uint_as_float(my_node | kLinkRefr));
+        if (sh.rng_out) sh.rng_out[slot] = o.rng_refr;
     }
 }
 
@@ -218,7 +225,7 @@ __device__ __forceinline__ void stamp(const LaunchParams& P, int tile, int k) {
 // time by p3d_set_tuning(); never changes results.
 #define P3D_OCC(OCC) __attribute__((amdgpu_waves_per_eu(OCC, 8)))
 
-template <bool COUNT, bool LDS, bool PACKET, int OCC>
+template <bool COUNT, bool LDS, bool PACKET, int OCC, bool STOCH = false>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel(const LaunchParams P) {
     const typename View<LDS>::type sv = View<LDS>::make(P);
     int x, y, row, tile;
@@ -235,7 +242,10 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel
     const Hit h = find_closest<COUNT, PACKET>(P, sv, ray, valid, tc, ctr);
     stamp(P, tile, 2);
     if (valid && P.hit_id && P.wf_sample == 0) P.hit_id[p] = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid;
-    const NodeOut o = shade_hit<COUNT, PACKET>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr);
+    // the random stream of a pixel sample is keyed by the pixel's place in the FULL frame, so a frame
+    // sharded over several GPUs draws the same numbers as on one
+    const uint32_t rng = STOCH ? rng_mix(rng_mix(P.seed, (uint32_t)(y * P.res_x + x)), (uint32_t)P.wf_sample) : 0u;
+    const NodeOut o = shade_hit<COUNT, PACKET, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr, rng);
     stamp(P, tile, 3);
     emit(P, sh, 1, valid, (uint32_t)p, 1.0f, o);
     stamp(P, tile, 4);
@@ -255,7 +265,7 @@ __device__ __forceinline__ uint32_t wave_width(uint32_t count, uint32_t waves_pe
 }
 
 // level >= 2: one queued ray per lane, persistent waves striding over the queue
-template <bool COUNT, bool LDS, bool PACKET, int OCC>
+template <bool COUNT, bool LDS, bool PACKET, int OCC, bool STOCH = false>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kernel(const LaunchParams P) {
     // wave g works on shard g % S; the (gridwaves / S) waves of a shard stride over its queue
     const uint32_t S = (uint32_t)P.wf_shards;
@@ -280,16 +290,18 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
     for (uint32_t base = (wave_id / S) * width; base < sh.count_in; base += per_shard * width) {
         const uint32_t i = base + lane;
         const bool valid = (uint32_t)lane < width && i < sh.count_in;
-        uint32_t link = 0; float ior_1 = 1.0f;
+        uint32_t link = 0, rng = 0; float ior_1 = 1.0f;
         Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
         if (valid) {
             const float4* rq = reinterpret_cast<const float4*>(sh.rays_in + i);
             float4 a = rq[0], b = rq[1];
             ray.o = mk(a.x, a.y, a.z); ray.d = mk(b.x, b.y, b.z);
             ior_1 = a.w; link = __float_as_uint(b.w);
+            if (STOCH) rng = sh.rng_in[i];
         }
         const Hit h = find_closest<COUNT, PACKET>(P, sv, ray, valid, tc, ctr);
-        const NodeOut o = shade_hit<COUNT, PACKET>(P, sv, ray, h, valid, P.wf_level, ior_1, tc, ctr);
+        const NodeOut o = shade_hit<COUNT, PACKET, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, P.wf_level, ior_1, tc,
+                                                                                  ctr, rng);
         emit(P, sh, P.wf_level, valid, link, ior_1, o);
     }
     flush_counters<COUNT>(P, ctr, 0u);
@@ -542,15 +554,33 @@ hipError_t launch_tree(const LaunchParams& P, bool count, bool lds, int occ, hip
         }                                                                                            \
     } while (0)
 
+// the variants with random draws (P.features != 0): default register budget only
+#define P3D_LAUNCH_WF_STOCH(KERNEL, count, lds, packet, grid, block, shmem, stream, P)                \
+    do {                                                                                             \
+        if (count) {                                                                                 \
+            if (lds) { if (packet) hipLaunchKernelGGL((KERNEL<true, true, true, 1, true>), grid, block, shmem, stream, P);   \
+                       else hipLaunchKernelGGL((KERNEL<true, true, false, 1, true>), grid, block, shmem, stream, P); }       \
+            else { if (packet) hipLaunchKernelGGL((KERNEL<true, false, true, 1, true>), grid, block, shmem, stream, P);      \
+                   else hipLaunchKernelGGL((KERNEL<true, false, false, 1, true>), grid, block, shmem, stream, P); }          \
+        } else {                                                                                     \
+            if (lds) { if (packet) hipLaunchKernelGGL((KERNEL<false, true, true, 1, true>), grid, block, shmem, stream, P);  \
+                       else hipLaunchKernelGGL((KERNEL<false, true, false, 1, true>), grid, block, shmem, stream, P); }      \
+            else { if (packet) hipLaunchKernelGGL((KERNEL<false, false, true, 1, true>), grid, block, shmem, stream, P);     \
+                   else hipLaunchKernelGGL((KERNEL<false, false, false, 1, true>), grid, block, shmem, stream, P); }         \
+        }                                                                                            \
+    } while (0)
+
 hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, bool packet, int occ, hipStream_t stream) {
     dim3 grid((unsigned)P.grid_blocks), block(64 * P.wg_waves);
-    P3D_LAUNCH_WF(wf_primary_kernel, count, lds, packet, occ, grid, block, wavefront_lds_bytes(P, lds), stream, P);
+    if (P.features) P3D_LAUNCH_WF_STOCH(wf_primary_kernel, count, lds, packet, grid, block, wavefront_lds_bytes(P, lds), stream, P);
+    else P3D_LAUNCH_WF(wf_primary_kernel, count, lds, packet, occ, grid, block, wavefront_lds_bytes(P, lds), stream, P);
     return hipGetLastError();
 }
 hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, bool packet, int occ, unsigned waves,
                                hipStream_t stream) {
     dim3 grid((waves + P.wg_waves - 1) / P.wg_waves), block(64 * P.wg_waves);
-    P3D_LAUNCH_WF(wf_secondary_kernel, count, lds, packet, occ, grid, block, wavefront_lds_bytes(P, lds), stream, P);
+    if (P.features) P3D_LAUNCH_WF_STOCH(wf_secondary_kernel, count, lds, packet, grid, block, wavefront_lds_bytes(P, lds), stream, P);
+    else P3D_LAUNCH_WF(wf_secondary_kernel, count, lds, packet, occ, grid, block, wavefront_lds_bytes(P, lds), stream, P);
     return hipGetLastError();
 }
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream) {

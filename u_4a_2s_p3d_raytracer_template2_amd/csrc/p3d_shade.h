@@ -103,7 +103,38 @@ struct NodeOut {
     bool has_refl, has_refr;
     Ray refl, refr;         // child rays; the reflection child keeps ior_1, the refraction child gets newIor
     float newIor;
+    uint32_t rng_refl, rng_refr;   // the children's random-stream keys (stochastic features only)
 };
+
+// ---- random numbers of the distribution-ray-tracing features
+// The reference draws from libc rand() inside the recursion, in pixel order: a serial stream no
+// parallel renderer can reproduce.  Here every rayTracing() invocation owns a 32-bit key -- the root's
+// is hash(seed, pixel, sample), a child's is hash(parent key, which child) -- and its k-th draw is
+// hash(key, k): the image is a pure function of (scene, camera, seed), independent of schedule,
+// sharding and launch order.  Parity with the reference is statistical (tests/test_gpu_distribution.py).
+__device__ __forceinline__ uint32_t rng_mix(uint32_t a, uint32_t b) {
+    uint32_t h = (a ^ 0x9E3779B9u) * 0x85EBCA6Bu + b;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ float rng_u01(uint32_t key, uint32_t k) {       // [0, 1), 24 bits like rand_float()
+    return (float)(rng_mix(key, k) >> 8) * (1.0f / 16777216.0f);
+}
+constexpr uint32_t kRngRefl = 0xA511E9B3u, kRngRefr = 0x63D83595u, kRngFuzzy = 0x40000000u;
+
+// position of light `light` as this invocation sees it: jittered over the reference's 0.5 x 0.5
+// area light, one stratum per pixel sample, when soft shadows run with anti-aliasing
+// (RT/main.cpp:621); the light's own position otherwise
+template <bool STOCH>
+__device__ __forceinline__ V3 light_position(const LaunchParams& P, float4 lpos, uint32_t light, uint32_t rng) {
+    if (STOCH && (P.features & kFeatSoftJitter)) {
+        const float offx = (float)(P.wf_sample / P.spp), offy = (float)(P.wf_sample % P.spp);   // RT/main.cpp:779-780
+        const float jx = fdiv(offx + rng_u01(rng, 2u * light), (float)P.spp);
+        const float jy = fdiv(offy + rng_u01(rng, 2u * light + 1u), (float)P.spp);
+        return mk(lpos.x + 0.5f * jx, lpos.y + 0.5f * jy, lpos.z);
+    }
+    return mk(lpos.x, lpos.y, lpos.z);
+}
 
 // colour returned by a node once its children returned refl_ret / refr_ret (zero when the
 // child was never traced): "color += reflection_color * KR * specColor + refraction_color *
@@ -116,11 +147,13 @@ __device__ __forceinline__ V3 combine_node(V3 color, float KR, V3 spec, V3 refl_
 // the shadow queries sit in wave-uniform control flow (the packet walk needs every lane of the
 // wave to arrive together): lanes without a ray or without a hit carry live == false /
 // hit == false through the light loop instead of leaving early.
-template <bool COUNT, bool PACKET, class SV>
+template <bool COUNT, bool PACKET, class SV, bool STOCH = false>
 __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv, const Ray& ray, const Hit& h,
-                                             bool live, int depth, float ior_1, const TravCtx& tc, Ctr& ctr) {
+                                             bool live, int depth, float ior_1, const TravCtx& tc, Ctr& ctr,
+                                             uint32_t rng = 0u) {
     NodeOut o;
     o.terminal = true; o.KR = 0.0f; o.mat = h.mat; o.has_refl = false; o.has_refr = false; o.newIor = 1.0f;
+    o.rng_refl = STOCH ? rng_mix(rng, kRngRefl) : 0u; o.rng_refr = STOCH ? rng_mix(rng, kRngRefr) : 0u;
     o.color = mk(0.0f, 0.0f, 0.0f);
     o.ret = o.color;
     o.refl.o = o.color; o.refl.d = o.color; o.refr.o = o.color; o.refr.d = o.color;
@@ -145,7 +178,7 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
         uint64_t occluded = 0;
         for (uint32_t i = 0; i < ln; i++) {
             const float4 lpos = reinterpret_cast<const float4*>(P.lights + l0 + i)[0];
-            V3 L = sub(mk(lpos.x, lpos.y, lpos.z), hit_point);
+            V3 L = sub(light_position<STOCH>(P, lpos, l0 + i, rng), hit_point);
             const bool need = hit && dot(L, normal) > 0.0f;              // RT/main.cpp:476
             if (light_occluded<COUNT, PACKET>(P, sv, L, precise, need, tc, ctr)) occluded |= (1ull << i);
         }
@@ -155,7 +188,7 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
                 if (occluded & (1ull << i)) continue;
                 const float4* lp = reinterpret_cast<const float4*>(P.lights + l0 + i);
                 float4 lpos = lp[0], lcol = lp[1];
-                V3 L = sub(mk(lpos.x, lpos.y, lpos.z), hit_point);
+                V3 L = sub(light_position<STOCH>(P, lpos, l0 + i, rng), hit_point);
                 light_term(L, mk(lcol.x, lcol.y, lcol.z), color, Ml, ray, normal);
             }
         }
@@ -176,7 +209,21 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
     if (M.refl > 0.0f) {                                                 // RT/main.cpp:646-667
         V3 rdir = sub(ray.d, mul(mul(normal, dot(ray.d, normal)), 2.0f));
         o.refl.o = precise;
-        o.refl.d = normalized(rdir);
+        if (STOCH && (P.features & kFeatFuzzy)) {                        // RT/main.cpp:651-660
+            // rnd_unit_sphere(), RT/maths.h:98-104: rejection sampling of the unit ball
+            V3 p; uint32_t k = kRngFuzzy;
+            do {
+                p = sub(mul(mk(rng_u01(rng, k), rng_u01(rng, k + 1u), rng_u01(rng, k + 2u)), 2.0f), mk(1.0f, 1.0f, 1.0f));
+                k += 3u;
+            } while (dot(p, p) >= 1.0f);
+            V3 sphere_center = add(rdir, precise);
+            V3 sphere_offset = add(sphere_center, mul(p, 0.3f));          // roughness 0.3
+            V3 fuzzy = normalized(sub(sphere_offset, precise));
+            // a rejected fuzzy direction leaves the mirror direction UN-normalised, as in the reference
+            o.refl.d = dot(fuzzy, normal) > 0.0f ? fuzzy : rdir;
+        } else {
+            o.refl.d = normalized(rdir);
+        }
         o.has_refl = true;
     }
     float KR;
