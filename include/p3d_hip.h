@@ -71,7 +71,10 @@ typedef struct p3d_scene_desc {
 typedef struct p3d_build_opts {
     uint32_t leaf_max;        /* max primitives per leaf, 1..8; 0 = default (4)          */
     uint32_t sah_bins;        /* 0 = default (16)                                       */
-    uint32_t reserved;        /* must be 0                                              */
+    uint32_t builder;         /* 0 = binned SAH on the host (default); 1 = linear BVH built on the
+                                 device (Morton sort + Karras hierarchy + refit): a tree of lower
+                                 quality in a fraction of the time, for scene-reload loops and
+                                 scenes of millions of primitives. Same images either way.     */
 } p3d_build_opts;
 
 /* The values Camera::Camera derives (RT/camera.h:35-73); PrimaryRay (RT/camera.h:91-127)

@@ -32,7 +32,7 @@ class SceneDesc(C.Structure):
 
 
 class BuildOpts(C.Structure):
-    _fields_ = [("leaf_max", C.c_uint32), ("sah_bins", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("leaf_max", C.c_uint32), ("sah_bins", C.c_uint32), ("builder", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -278,17 +278,18 @@ def make_desc(ptype, data12, material, materials12, lights6, bg):
 class DeviceScene:
     """p3d_scene on one GPU."""
 
-    def __init__(self, desc, device=0, leaf_max=0, keepalive=None):
+    def __init__(self, desc, device=0, leaf_max=0, keepalive=None, builder=0):
+        """builder: 0 = host SAH, 1 = device LBVH (p3d_build_opts.builder)."""
         self._keep = keepalive
         self.h = C.c_void_p()
-        opts = BuildOpts(leaf_max, 0, 0)
+        opts = BuildOpts(leaf_max, 0, builder)
         _check(lib().p3d_scene_create(C.byref(desc), C.byref(opts), int(device), C.byref(self.h)),
                "p3d_scene_create")
         self.device = device
 
     @classmethod
-    def from_host(cls, hs, device=0, leaf_max=0):
-        return cls(hs.desc(), device, leaf_max, keepalive=hs)
+    def from_host(cls, hs, device=0, leaf_max=0, builder=0):
+        return cls(hs.desc(), device, leaf_max, keepalive=hs, builder=builder)
 
     def close(self):
         if self.h:

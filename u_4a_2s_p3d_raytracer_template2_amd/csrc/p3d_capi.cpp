@@ -28,6 +28,8 @@ hipError_t launch_raygen_table(float* fx, float* fy, int res_x, int res_y, hipSt
 hipError_t prepare_kernels(size_t max_lds);
 hipError_t launch_deinterleave(const void* gathered, void* frame, int res_x, int res_y, int row_block,
                                int world, size_t rank_stride, int bpp, hipStream_t stream);
+hipError_t build_lbvh_device(const std::vector<BuildPrim>& prims, const BvhOptions& opt, NodePair* d_nodes,
+                             uint32_t* d_refs, BvhStats& stats, hipStream_t stream);
 hipError_t launch_debug_intersect(uint32_t n, const uint32_t* type, const float* prim12, const float* origin,
                                   const float* dir, int32_t* hit, float* t, float* normal, hipStream_t stream);
 }  // namespace p3d
@@ -170,7 +172,16 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
         if (opts->sah_bins) bo.bins = opts->sah_bins;
     }
     std::vector<NodePair> nodes; std::vector<uint32_t> refs; BvhStats bs;
-    build_bvh(F.build_prims, bo, nodes, refs, bs);
+    if (opts && opts->builder > 1) return fail(P3D_ERR_ARG, "builder must be 0 (host SAH) or 1 (device LBVH)");
+    // the device builder needs at least two leaves; tiny scenes are built on the host either way
+    const bool device_build = opts && opts->builder == 1 && F.build_prims.size() >= 64;
+    if (device_build) {
+        // sections of the right size, filled in by build_lbvh_device() once the blob is on the device
+        nodes.assign((F.build_prims.size() + 1) / 2 - 1, NodePair());
+        refs.assign(F.build_prims.size(), 0u);
+    } else {
+        build_bvh(F.build_prims, bo, nodes, refs, bs);
+    }
     std::vector<SphereRec>& spheres = F.spheres; std::vector<PrimMeta>& sphere_meta = F.sphere_meta;
     std::vector<TriRec>& tris = F.tris; std::vector<BoxRec>& boxes = F.boxes;
     std::vector<PlaneRec>& planes = F.planes; std::vector<PrimMeta>& plane_meta = F.plane_meta;
@@ -209,6 +220,12 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
         s->off_mats = section(mats.data(), mats.size() * sizeof(MaterialRec));
         s->blob_quads = (uint32_t)(blob.size() / 4);
         if ((e = s->blob.upload(blob)) != hipSuccess) return bail(e, "upload scene blob");
+    }
+    if (device_build) {
+        NodePair* d_nodes = reinterpret_cast<NodePair*>(s->blob.p + (size_t)s->off_nodes * 4);
+        uint32_t* d_refs = s->blob.p + (size_t)s->off_refs * 4;
+        if ((e = build_lbvh_device(F.build_prims, bo, d_nodes, d_refs, bs, s->own_stream)) != hipSuccess)
+            return bail(e, "device BVH build");
     }
     if ((e = s->planes.upload(planes)) != hipSuccess) return bail(e, "upload planes");
     if ((e = s->plane_meta.upload(plane_meta)) != hipSuccess) return bail(e, "upload plane meta");
