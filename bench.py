@@ -178,9 +178,13 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-step", type=int, default=12)
-    ap.add_argument("--frames-in-flight", type=int, default=3,
+    ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frames overlapped on separate HIP streams (each with its own scene handle "
-                         "and workspace); 1 = strictly one frame after the other")
+                         "and workspace); 1 = strictly one frame after the other; default 3 per GPU-th of a frame "
+                         "(3 on one GPU, min(frames-per-step, 3 N) when the frame is tiled over N GPUs)")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the frames of a step as ONE captured HIP graph instead of ~8 launches per frame "
+                         "(auto: use it when capture succeeds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["config2", "pathtracer", "synthetic"], default="config2",
                     help="config2 = the headline Whitted frame; pathtracer = BASELINE config 5 (P3D_RT.glsl scene, "
@@ -249,7 +253,10 @@ def main():
     # The deeper tree levels of one 1080p frame are too few rays to fill 256 CUs (each level launch is
     # bounded by single-wave latency), so consecutive frames -- independent work, exactly like the
     # reference's render-another-image loop -- are overlapped on F streams, one scene handle each.
-    F = max(1, min(args.frames_in_flight, args.frames_per_step))
+    # With the frame tiled over N GPUs each rank holds 1/N of every frame, so it takes N times as many
+    # frames in flight to fill it.
+    F = args.frames_in_flight if args.frames_in_flight > 0 else 3 * world
+    F = max(1, min(F, args.frames_per_step))
     main_stream = torch.cuda.current_stream()
     streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
     handles = []
@@ -278,14 +285,48 @@ def main():
     px_local = ctr["pixels"]
     alg_bytes = ctr["algorithmic_bytes"] + 3 * px_local          # + rgb8 written per pixel
 
-    def step():
-        for k in range(1, F):                       # side streams start after whatever the main stream holds
-            streams[k].wait_stream(main_stream)
+    def render_frames(lead):
+        """The B frames of a step: fork the side streams off `lead`, enqueue, join back into `lead`."""
+        for k in range(1, F):
+            streams[k].wait_stream(lead)
         for f in range(B):
             handles[f % F].render_device(cam, rgb8_ptr=tiles[f].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
                                          rank=rank, world=world, row_block=ROW_BLOCK, **sched)
-        for k in range(1, F):                       # ... and the main stream continues after all frames
-            main_stream.wait_stream(streams[k])
+        for k in range(1, F):
+            lead.wait_stream(streams[k])
+
+    # A step is ~8 launches per frame; at a fraction of a millisecond per step the host's launch rate
+    # matters, most of all when N GPUs each hold 1/N of the work.  The frames of a step are captured once
+    # into a HIP graph (after an eager step has sized every workspace) and replayed with one launch.
+    graph = None
+    # On one GPU the step is GPU-bound and eager launches measured marginally faster (42.6 vs 40.8 Grays/s),
+    # so "auto" captures only when the frame is tiled over several GPUs.
+    want_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
+    if want_graph and not (synthetic and args.schedule == "default"):     # the schedule pick reads events: eager only
+        try:
+            render_frames(main_stream)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                lead = torch.cuda.current_stream()
+                handles[0].set_stream(lead.cuda_stream)
+                render_frames(lead)
+            handles[0].set_stream(main_stream.cuda_stream)
+            g.replay()
+            torch.cuda.synchronize()
+            graph = g
+        except Exception as exc:                     # capture not possible here: keep launching eagerly
+            handles[0].set_stream(main_stream.cuda_stream)
+            if args.graph == "on":
+                raise
+            if rank == 0:
+                print("bench.py: HIP graph capture unavailable (%s); launching eagerly" % exc, file=sys.stderr)
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            render_frames(main_stream)
         if world > 1:
             if rehearsal:
                 torch.cuda.synchronize()
@@ -375,7 +416,8 @@ def main():
                     "synthetic: P3D_Scenes/mount_low.p3f (12 primitives, 1 light) resolution/accel overridden to the config",
             "config": {"workload": ("SURVEY 8d scaling scene, %d primitives, 1920x1080 depth 4 BVH" % args.prims) if synthetic
                        else "mount_low.p3f 1920x1080 depth 4 BVH (BASELINE config 2)",
-                       "frames_per_step": B, "frames_in_flight": F, "rays_per_frame": int(rays_frame),
+                       "frames_per_step": B, "frames_in_flight": F, "hip_graph": graph is not None,
+                       "rays_per_frame": int(rays_frame),
                        "row_block": ROW_BLOCK,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved 16-row blocks + RCCL gather to rank 0" % world,
                        "frame_checksum": int(final.astype(np.uint64).sum())},
