@@ -307,7 +307,8 @@ def main():
             render_frames(main_stream)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: RCCL's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 lead = torch.cuda.current_stream()
                 handles[0].set_stream(lead.cuda_stream)
                 render_frames(lead)
