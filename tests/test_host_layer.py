@@ -179,3 +179,28 @@ def test_no_device_is_an_error_not_a_fallback():
     with pytest.raises(P.P3DError) as e:
         P.DeviceScene.from_host(hs)
     assert "device" in str(e.value).lower()
+
+
+def test_png_writer_round_trip(tmp_path):
+    """saveImgFile() replacement (RT/main.cpp:261-276): a valid PNG whose rows are img_Data top-down."""
+    import struct, zlib
+    from u_4a_2s_p3d_raytracer_template2_amd import api
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (37, 211, 3), dtype=np.uint8)          # > 65535 raw bytes: several stored blocks
+    path = str(tmp_path / "RT_Output.png")
+    api.save_png(path, img)
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, chunks = 8, []
+    while at < len(data):
+        n, typ = struct.unpack(">I4s", data[at:at + 8])
+        body = data[at + 8:at + 8 + n]
+        (crc,) = struct.unpack(">I", data[at + 8 + n:at + 12 + n])
+        assert crc == zlib.crc32(typ + body) & 0xFFFFFFFF
+        chunks.append((typ, body)); at += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, colour, _, _, _ = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (w, h, depth, colour) == (211, 37, 8, 2)
+    raw = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(37, 1 + 211 * 3)
+    assert (raw[:, 0] == 0).all()
+    assert np.array_equal(raw[:, 1:].reshape(37, 211, 3), img[::-1])

@@ -401,6 +401,16 @@ def debug_intersect(ptype, prim12, origin, direction, device=0):
     return hit.astype(bool), t, nrm
 
 
+def save_png(path, rgb8):
+    """RT_Output.png writer of the host layer (csrc/host/p3d_scene.cpp): rgb8 is [H, W, 3] u8, bottom row first."""
+    img = np.ascontiguousarray(rgb8, np.uint8)
+    L = lib()
+    L.p3dh_save_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+    L.p3dh_save_png.restype = C.c_int
+    if L.p3dh_save_png(os.fsencode(path), img.ctypes.data, img.shape[1], img.shape[0]) != 0:
+        raise P3DError("cannot write %s" % path)
+
+
 def host_bvh(desc, leaf_max=0):
     """Host-only BVH build (no GPU): dict(nodes [n,16] u32 view, refs, info)."""
     h = lib().p3dh_bvh_build(C.byref(desc), int(leaf_max))

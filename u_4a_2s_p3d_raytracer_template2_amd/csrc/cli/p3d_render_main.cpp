@@ -1,7 +1,7 @@
 // p3d_render -- command-line front end: the offline branch of the reference's main()
 // (RT/main.cpp:949-976: init_scene -> renderScene -> save image) on an MI355X.
 //   p3d_render <scene.p3f> [--res W H] [--accel 0|1|2] [--depth D] [--spp N] [--seed S]
-//              [--device K] [--out image.ppm] [--counters]
+//              [--device K] [--out image.png|image.ppm] [--counters] [--soft-shadow] [--fuzzy-reflection]
 // Defaults are the reference's: resolution / accel / spp from the file, MAX_DEPTH 4.
 #include <chrono>
 #include <cstdio>
@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     }
     RenderOptions opt;
     int rw = 0, rh = 0;
-    std::string out = "RT_Output.ppm";
+    std::string out = "RT_Output.png";                       // the reference's file name, RT/main.cpp:968
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
         auto need = [&](int n) { if (i + n >= argc) { fprintf(stderr, "%s needs %d value(s)\n", a.c_str(), n); exit(2); } };
@@ -67,7 +67,9 @@ int main(int argc, char** argv) {
                (unsigned long long)res.counters.box_tests, (unsigned long long)res.counters.sphere_tests,
                (unsigned long long)res.counters.tri_tests);
     }
-    if (save_ppm(out.c_str(), res.img_Data, scene.GetCamera()->GetResX(), scene.GetCamera()->GetResY())) {
+    const int W = scene.GetCamera()->GetResX(), H = scene.GetCamera()->GetResY();
+    const bool ppm = out.size() > 4 && out.compare(out.size() - 4, 4, ".ppm") == 0;
+    if (ppm ? save_ppm(out.c_str(), res.img_Data, W, H) : save_png(out.c_str(), res.img_Data.data(), W, H)) {
         fprintf(stderr, "Error saving Image file\n");
         return 1;
     }

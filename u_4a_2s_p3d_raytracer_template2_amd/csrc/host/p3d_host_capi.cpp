@@ -57,6 +57,9 @@ struct p3dh_bvh {
     std::vector<p3d::BuildPrim> prims;   // padded bounds, in the builder's final order
     p3d::BvhStats stats;
 };
+// saveImgFile() replacement, exposed for the CPU-side tests
+int p3dh_save_png(const char* path, const uint8_t* img_Data, int32_t w, int32_t h) { return save_png(path, img_Data, w, h); }
+
 p3dh_bvh* p3dh_bvh_build(const p3d_scene_desc* d, uint32_t leaf_max) {
     p3d::FlatScene F;
     if (!p3d::flatten_scene(*d, F).empty()) return nullptr;

@@ -294,6 +294,70 @@ void generate_samples(unsigned seed, int res_x, int res_y, int spp, float apertu
                 }
 }
 
+// ---------------------------------------------------------------- PNG output (RT/main.cpp:261-276)
+namespace {
+uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {
+    static uint32_t table[256];
+    if (!table[1]) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+    }
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+void put_chunk(std::vector<uint8_t>& out, const char type[4], const std::vector<uint8_t>& data) {
+    put_be32(out, (uint32_t)data.size());
+    size_t at = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    put_be32(out, crc32_update(0xFFFFFFFFu, out.data() + at, out.size() - at) ^ 0xFFFFFFFFu);
+}
+}  // namespace
+
+int save_png(const char* path, const uint8_t* img, int w, int h) {
+    if (!path || !img || w <= 0 || h <= 0) return -1;
+    // raw scanlines: filter byte 0 + RGB, top row first (img_Data is bottom row first, RT/main.cpp:76)
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)h * (3 * (size_t)w + 1));
+    for (int y = h - 1; y >= 0; y--) {
+        raw.push_back(0);
+        raw.insert(raw.end(), img + (size_t)y * w * 3, img + (size_t)(y + 1) * w * 3);
+    }
+    // zlib stream of stored blocks (<= 65535 bytes each) + Adler-32
+    std::vector<uint8_t> z;
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t at = 0; at < raw.size() || at == 0;) {
+        const size_t n = std::min<size_t>(65535, raw.size() - at);
+        const bool last = at + n >= raw.size();
+        z.push_back(last ? 1 : 0);
+        z.push_back((uint8_t)n); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)~n); z.push_back((uint8_t)(~n >> 8));
+        z.insert(z.end(), raw.begin() + at, raw.begin() + at + n);
+        for (size_t i = at; i < at + n; i++) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        at += n;
+        if (last) break;
+    }
+    put_be32(z, (b << 16) | a);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, (uint32_t)w); put_be32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);   // 8-bit RGB
+    put_chunk(out, "IHDR", ihdr);
+    put_chunk(out, "IDAT", z);
+    put_chunk(out, "IEND", std::vector<uint8_t>());
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    return (fclose(f) == 0 && ok) ? 0 : -1;
+}
+
 // ---------------------------------------------------------------- renderScene drop-in
 int renderScene(const Scene& scene, const RenderOptions& opt, bool want_colors, bool want_hit, RenderResult& out,
                 std::string* err) {

@@ -225,6 +225,11 @@ struct RenderResult {
     p3d_counters counters{};
     float kernel_ms = 0;
 };
+// saveImgFile("RT_Output.png") of RT/main.cpp:261-276 without DevIL: 8-bit RGB PNG, one IDAT of stored
+// (uncompressed) deflate blocks.  img_Data is bottom row first; the file is written top row first.
+// Returns 0, or -1 when the file cannot be written.
+int save_png(const char* path, const uint8_t* img_Data, int width, int height);
+
 int renderScene(const Scene& scene, const RenderOptions& opt, bool want_colors, bool want_hit, RenderResult& out,
                 std::string* err);
 
