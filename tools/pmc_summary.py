@@ -18,8 +18,9 @@ from collections import defaultdict
 
 
 def short(name):
-    name = re.sub(r"\(.*$", "", name)
-    return re.sub(r"<.*$", "", name)
+    # keep the template arguments: the counting builds (<true, ...>) are different, much slower kernels
+    name = re.sub(r"\(p3d::LaunchParams\)$", "", name)
+    return re.sub(r"^void ", "", name)
 
 
 def main():
