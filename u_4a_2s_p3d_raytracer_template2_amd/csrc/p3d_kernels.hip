@@ -259,8 +259,11 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel
 // each other's memory latency.  Scenes served from LDS keep full waves (wf_min_width = 64):
 // there the extra waves only cost issue slots (measured: 0.14 -> 0.20 ms on config 2).
 __device__ __forceinline__ uint32_t wave_width(uint32_t count, uint32_t waves_per_shard, uint32_t min_width) {
+    // narrow only while the rays still fit the waves that can be RESIDENT at once (a quarter of the
+    // launched ones): beyond that, narrower waves just spend issue slots on idle lanes
+    const unsigned long long resident = waves_per_shard >= 4 ? waves_per_shard / 4 : 1;
     uint32_t width = 64;
-    while (width > min_width && (unsigned long long)waves_per_shard * (width >> 1) >= count) width >>= 1;
+    while (width > min_width && resident * (width >> 1) >= count) width >>= 1;
     return width;
 }
 
