@@ -39,7 +39,8 @@ struct Builder {
 
     int32_t make_leaf(size_t b, size_t e, uint32_t depth, const Box& box) {
         std::sort(P.begin() + b, P.begin() + e,
-                  [](const BuildPrim& x, const BuildPrim& y) { return x.scene_id < y.scene_id; });
+                  [](const BuildPrim& x, const BuildPrim& y) { return x.ref < y.ref; });   // kind-major: the
+        // lanes of a wave then mostly run the same intersector in the same leaf-loop iteration
         uint32_t first = (uint32_t)refs.size();
         for (size_t i = b; i < e; i++) refs.push_back(P[i].ref);
         st.n_leaves++;

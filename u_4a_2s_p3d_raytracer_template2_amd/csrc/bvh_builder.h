@@ -30,8 +30,8 @@ struct BvhOptions {
     float cost_intersect = 1.0f;
 };
 
-// nodes[0] is always an inner node (the root); leaf_refs is grouped per leaf and sorted by
-// scene id inside a leaf.
+// nodes[0] is always an inner node (the root); leaf_refs is grouped per leaf, kind-major inside a
+// leaf (ascending ref).
 void build_bvh(std::vector<BuildPrim>& prims, const BvhOptions& opt,
                std::vector<NodePair>& nodes, std::vector<uint32_t>& leaf_refs, BvhStats& stats);
 
