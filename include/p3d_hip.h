@@ -75,6 +75,16 @@ typedef struct p3d_build_opts {
                                  device (Morton sort + Karras hierarchy + refit): a tree of lower
                                  quality in a fraction of the time, for scene-reload loops and
                                  scenes of millions of primitives. Same images either way.     */
+    uint32_t cull_never_hit;  /* 1 = leave out of the BVH every triangle the reference's own test can
+                                 never accept: Triangle::intercepts rejects |det| < 1e-3
+                                 (RT/scene.cpp:66-67) and |det| <= |d| * |e1 x e2|, so a
+                                 triangle with sqrt(2) * |e1 x e2| below that threshold is invisible to
+                                 every ray whose direction is at most sqrt(2) long -- all closest-hit
+                                 rays (the odd refraction ray of SURVEY Q6 reaches sqrt(2)) and the
+                                 normalised shadow rays of GRID / BVH mode. NONE-mode shadow rays are
+                                 not normalised, so p3d_render() rejects accel NONE on such a scene.
+                                 Same images, same ray counts, fewer box / triangle tests. Default 0:
+                                 every primitive is traversed, like in the reference.            */
 } p3d_build_opts;
 
 /* The values Camera::Camera derives (RT/camera.h:35-73); PrimaryRay (RT/camera.h:91-127)

@@ -84,3 +84,32 @@ def test_device_built_bvh_gives_the_same_frames(tmp_path):
     c = P.DeviceScene.from_host(hs, builder=1); d = P.DeviceScene.from_host(hs, builder=0)
     assert c.stats()["n_nodes"] == d.stats()["n_nodes"]
     c.close(); d.close()
+
+
+def test_cull_never_hit_is_invisible_in_the_output():
+    """p3d_build_opts.cull_never_hit: triangles the reference's |det| < 1e-3 test can never accept
+    are left out of the BVH.  Frames and ray counts must not change; NONE mode (un-normalised shadow rays)
+    is refused."""
+    hs = P.HostScene(scene_path("dragon")); hs.set_resolution(320, 180)
+    cam = hs.camera()
+    full = P.DeviceScene.from_host(hs)
+    lean = P.DeviceScene.from_host(hs, cull_never_hit=True)
+    assert full.stats()["n_culled"] == 0
+    assert lean.stats()["n_culled"] > 90000 and lean.stats()["n_nodes"] < full.stats()["n_nodes"] // 10
+    for accel in (2, 1):
+        for kw in (dict(wavefront=True), dict(tree=True)):
+            a = full.render(cam, max_depth=4, accel=accel, counters=True, **kw)
+            b = lean.render(cam, max_depth=4, accel=accel, counters=True, **kw)
+            assert np.array_equal(a["hit_id"], b["hit_id"])
+            assert np.array_equal(a["rgb32f"], b["rgb32f"], equal_nan=True)
+            assert a["counters"]["rays"] == b["counters"]["rays"]
+            assert b["counters"]["tri_tests"] < a["counters"]["tri_tests"] // 2 and b["counters"]["box_tests"] < a["counters"]["box_tests"] // 2
+    with pytest.raises(P.P3DError):
+        lean.render(cam, max_depth=4, accel=0)
+    full.close(); lean.close()
+    # a scene with ordinary triangles loses nothing
+    hs = P.HostScene(scene_path("mount_low"))
+    ds = P.DeviceScene.from_host(hs, cull_never_hit=True)
+    assert ds.stats()["n_culled"] == 0
+    ds.render(hs.camera(), accel=0)
+    ds.close()

@@ -32,7 +32,7 @@ class SceneDesc(C.Structure):
 
 
 class BuildOpts(C.Structure):
-    _fields_ = [("leaf_max", C.c_uint32), ("sah_bins", C.c_uint32), ("builder", C.c_uint32)]
+    _fields_ = [("leaf_max", C.c_uint32), ("sah_bins", C.c_uint32), ("builder", C.c_uint32), ("cull_never_hit", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -278,18 +278,18 @@ def make_desc(ptype, data12, material, materials12, lights6, bg):
 class DeviceScene:
     """p3d_scene on one GPU."""
 
-    def __init__(self, desc, device=0, leaf_max=0, keepalive=None, builder=0):
-        """builder: 0 = host SAH, 1 = device LBVH (p3d_build_opts.builder)."""
+    def __init__(self, desc, device=0, leaf_max=0, keepalive=None, builder=0, cull_never_hit=False):
+        """builder: 0 = host SAH, 1 = device LBVH; cull_never_hit: see p3d_build_opts in p3d_hip.h."""
         self._keep = keepalive
         self.h = C.c_void_p()
-        opts = BuildOpts(leaf_max, 0, builder)
+        opts = BuildOpts(leaf_max, 0, builder, 1 if cull_never_hit else 0)
         _check(lib().p3d_scene_create(C.byref(desc), C.byref(opts), int(device), C.byref(self.h)),
                "p3d_scene_create")
         self.device = device
 
     @classmethod
-    def from_host(cls, hs, device=0, leaf_max=0, builder=0):
-        return cls(hs.desc(), device, leaf_max, keepalive=hs, builder=builder)
+    def from_host(cls, hs, device=0, leaf_max=0, builder=0, cull_never_hit=False):
+        return cls(hs.desc(), device, leaf_max, keepalive=hs, builder=builder, cull_never_hit=cull_never_hit)
 
     def close(self):
         if self.h:

@@ -99,6 +99,7 @@ struct p3d_scene {
     std::vector<LightRec> host_lights;
     size_t lds_scene_limit = 24 * 1024;  // blobs up to this size are rendered from an LDS copy
     int last_schedule = -1;
+    bool unit_rays_only = false;         // built with cull_never_hit: cannot serve un-normalised (NONE-mode) shadow rays
     size_t tree_blob_limit = (size_t)2 << 20;   // scenes above this pick their schedule by measurement
     uint32_t packet_node_limit = 64;     // trees up to this many node pairs use the wave-wide walk
     float bg[3] = {0, 0, 0};
@@ -171,6 +172,28 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
         if (opts->leaf_max) bo.leaf_max = std::min<uint32_t>(opts->leaf_max, 8);
         if (opts->sah_bins) bo.bins = opts->sah_bins;
     }
+    // optional: triangles no ray of length <= sqrt(2) can hit (see p3d_build_opts::cull_never_hit).
+    // Bound on the FLOAT determinant the reference computes: |det| <= |d| (|e1 x e2| + 1e-6 |e1| |e2|)
+    // (products and sums of RT/scene.cpp:64-65 each round once, 6e-8 relative; 1e-6 covers them all).
+    uint32_t n_culled = 0;
+    if (opts && opts->cull_never_hit) {
+        std::vector<BuildPrim> kept;
+        kept.reserve(F.build_prims.size());
+        for (const BuildPrim& b : F.build_prims) {
+            bool never = false;
+            if ((b.ref >> kRefKindShift) == 1u) {
+                const TriRec& t = F.tris[b.ref & kRefIndexMask];
+                const double e1[3] = {t.e1[0], t.e1[1], t.e1[2]}, e2[3] = {t.e2[0], t.e2[1], t.e2[2]};
+                const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                const double cross = std::sqrt(cx * cx + cy * cy + cz * cz);
+                const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+                const double l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+                never = 1.41422 * (cross + 1e-6 * l1 * l2) < 0.999e-3;
+            }
+            if (never) n_culled++; else kept.push_back(b);
+        }
+        F.build_prims.swap(kept);
+    }
     std::vector<NodePair> nodes; std::vector<uint32_t> refs; BvhStats bs;
     if (opts && opts->builder > 1) return fail(P3D_ERR_ARG, "builder must be 0 (host SAH) or 1 (device LBVH)");
     // the device builder needs at least two leaves; tiny scenes are built on the host either way
@@ -239,7 +262,8 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     s->stats.n_leaf_refs = bs.n_leaf_refs; s->stats.sah_cost = bs.sah_cost;
     s->stats.n_spheres = (uint32_t)spheres.size(); s->stats.n_triangles = (uint32_t)tris.size();
     s->stats.n_boxes = (uint32_t)boxes.size(); s->stats.n_planes = (uint32_t)planes.size();
-    s->stats.n_culled = 0;
+    s->stats.n_culled = n_culled;
+    s->unit_rays_only = n_culled > 0;
     s->stats.device_bytes = s->blob.bytes() + s->planes.bytes() + s->plane_meta.bytes() + s->lights.bytes();
     *out = s;
     return P3D_OK;
@@ -356,6 +380,8 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     if (cam->res_x <= 0 || cam->res_y <= 0) return fail(P3D_ERR_ARG, "bad resolution");
     if (prm->max_depth < 1 || prm->max_depth > 16) return fail(P3D_ERR_ARG, "max_depth must be in 1..16");
     if (prm->accel < 0 || prm->accel > 2) return fail(P3D_ERR_ARG, "accel must be 0, 1 or 2");
+    if (s->unit_rays_only && prm->accel == P3D_ACCEL_NONE)
+        return fail(P3D_ERR_STATE, "scene was built with cull_never_hit: accel NONE (un-normalised shadow rays) is not served");
     if (prm->spp < 0 || prm->spp > 8) return fail(P3D_ERR_ARG, "spp must be in 0..8");
     if (prm->spp > 0 && !prm->samples) return fail(P3D_ERR_ARG, "spp > 0 needs the host sample array");
     int world = prm->world > 0 ? prm->world : 1;
