@@ -19,10 +19,6 @@ struct NodePair {
 };
 static_assert(sizeof(NodePair) == 64, "NodePair must be 64 bytes");
 
-// One wave (64 lanes = a 16x4 pixel tile) per workgroup: a wave's LDS and wave slot free up
-// the moment its own ray trees finish, instead of waiting for three neighbours.
-constexpr int kWavesPerGroup = 1;
-
 // leaf reference: kind in the top 2 bits, index into that kind's array below
 constexpr uint32_t kRefKindShift = 30;
 constexpr uint32_t kRefIndexMask = (1u << kRefKindShift) - 1u;
