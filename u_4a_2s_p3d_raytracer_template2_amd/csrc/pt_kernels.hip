@@ -325,14 +325,20 @@ struct PtLaunch {
     float* rgba; float* linear;
 };
 
-__global__ __launch_bounds__(256) void pt_frames_kernel(const PtLaunch P) {
+// One wave (a 16x4 pixel strip) per workgroup: a wave keeps its pixels for all n_frames frames, so its
+// run time varies a lot from strip to strip; with four waves per workgroup the wave slots of the early
+// finishers stayed reserved until the slowest one was done.  PT_WAVES_PER_EU caps the register budget.
+#ifndef PT_WAVES_PER_EU
+#define PT_WAVES_PER_EU 5
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU, 8))) void pt_frames_kernel(const PtLaunch P) {
     __shared__ SmallSphere tab[100];
-    __shared__ int wave_union[4 * 4];      // per wave: cell range union scratch (hit_world)
+    __shared__ int wave_union[4];          // cell range union scratch of this wave (hit_world)
     build_small_spheres(tab);
     __syncthreads();
     const int tiles_x = (P.ires_x + 15) / 16;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int x = tx * 16 + (threadIdx.x & 15), y = ty * 16 + (threadIdx.x >> 4);
+    const int x = tx * 16 + (threadIdx.x & 15), y = ty * 4 + (threadIdx.x >> 4);
     if (x >= P.ires_x || y >= P.ires_y) return;
     const float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;                 // gl_FragCoord
     const float pix_hash = (float)base_hash(__float_as_uint(fcx), __float_as_uint(fcy)) / (float)0xffffffffU;
@@ -374,8 +380,8 @@ __global__ void pt_hash_kernel(uint32_t n, const uint32_t* a, const uint32_t* b,
 }
 
 hipError_t launch_pt_frames(const PtLaunch& P, hipStream_t stream) {
-    const int tiles = ((P.ires_x + 15) / 16) * ((P.ires_y + 15) / 16);
-    hipLaunchKernelGGL(pt_frames_kernel, dim3(tiles), dim3(256), 0, stream, P);
+    const int tiles = ((P.ires_x + 15) / 16) * ((P.ires_y + 3) / 4);
+    hipLaunchKernelGGL(pt_frames_kernel, dim3(tiles), dim3(64), 0, stream, P);
     return hipGetLastError();
 }
 hipError_t launch_pt_hash(uint32_t n, const uint32_t* a, const uint32_t* b, uint32_t* out, hipStream_t stream) {
