@@ -151,7 +151,10 @@ __device__ __forceinline__ Mat small_sphere_material(int cls, float seed) {
 }
 
 // hit_world, PT/P3D_RT.glsl:12-180
-__device__ __forceinline__ bool hit_world(const SmallSphere* tab, int* wave_union, float& gSeed, const Ray& r, float tmin, float tmax, Rec& rec) {
+// which of the 100 cells hold a sphere at all / a moving one (class 0): wave-uniform bit sets
+struct SphereSets { uint64_t present_lo, present_hi, moving_lo, moving_hi; };
+
+__device__ __forceinline__ bool hit_world(const SmallSphere* tab, const SphereSets& sets, int* wave_union, float& gSeed, const Ray& r, float tmin, float tmax, Rec& rec) {
     bool hit = false;
     rec.t = tmax;
     if (hit_triangle(F3(-10.0f, -0.01f, 10.0f), F3(10.0f, -0.01f, 10.0f), F3(-10.0f, -0.01f, -10.0f), r, tmin, rec.t, rec)) { hit = true; rec.m = diffuse_mat(F3(0.2f, 0.2f, 0.2f)); }
@@ -204,16 +207,31 @@ __device__ __forceinline__ bool hit_world(const SmallSphere* tab, int* wave_unio
         iz0 = __builtin_amdgcn_readfirstlane(((volatile int*)u)[2]); iz1 = __builtin_amdgcn_readfirstlane(((volatile int*)u)[3]);
         __builtin_amdgcn_wave_barrier();
     }
+    // The cells to look at, as a wave-uniform 100-bit set (two scalar registers pairs): every MOVING
+    // sphere (its two RNG draws happen whether or not it is near, in index order) plus the present
+    // spheres inside the union rectangle.  Walking the set bits instead of all 100 cells removes the
+    // LDS read + scalar branch the culled cells used to cost.
+    uint64_t near_lo = 0, near_hi = 0;
+    if (ix0 <= ix1 && iz0 <= iz1) {
+        const uint64_t row = ((1ull << (iz1 - iz0 + 1)) - 1ull) << (iz0 + 5);          // <= 10 bits
+        for (int gx = ix0; gx <= ix1; gx++) {
+            const int o = (gx + 5) * 10;
+            if (o < 64) { near_lo |= row << o; if (o > 54) near_hi |= row >> (64 - o); }
+            else near_hi |= row << (o - 64);
+        }
+    }
+    near_lo &= sets.present_lo; near_hi &= sets.present_hi;
     int best = -1;
-    for (int gx = -5; gx < 5; gx++) {
-        const bool xin = gx >= ix0 && gx <= ix1;
-        for (int gz = -5; gz < 5; gz++) {
-            const int i = (gx + 5) * 10 + (gz + 5);
-            const int cls = __builtin_amdgcn_readfirstlane(tab[i].cls);
-            if (cls < 0) continue;
-            const bool near = xin && gz >= iz0 && gz <= iz1;          // wave-uniform
+    for (int half = 0; half < 2; half++) {
+        const uint64_t near_m = half ? near_hi : near_lo, moving_m = half ? sets.moving_hi : sets.moving_lo;
+        uint64_t todo = near_m | moving_m;
+        while (todo) {
+            const int b = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int i = half * 64 + b;
+            const bool near = (near_m >> b) & 1ull, moving = (moving_m >> b) & 1ull;     // wave-uniform
             float h = 0.0f;
-            if (cls == 0) {        // motion blur: centre interpolated towards a RANDOM centre1, drawn per call
+            if (moving) {          // motion blur: centre interpolated towards a RANDOM centre1, drawn per call
                 gSeed += 0.1f; const float sa = gSeed;
                 gSeed += 0.1f; const float sb = gSeed;
                 if (near) h = (float)base_hash(__float_as_uint(sa), __float_as_uint(sb)) / (float)0xffffffffU;   // hash1(gSeed)
@@ -221,11 +239,11 @@ __device__ __forceinline__ bool hit_world(const SmallSphere* tab, int* wave_unio
             if (!near) continue;
             const SmallSphere s = tab[i];
             f3 c = F3(s.cx, s.cy, s.cz);
-            if (cls == 0) {
+            if (moving) {
                 const f3 c1 = c + F3(0.0f, h * 0.5f, 0.0f);
                 c = c + (c1 - c) * ((r.t - 0.0f) / (1.0f - 0.0f));
             }
-            if (hit_sphere(c, 0.2f, cls == 0, r, tmin, rec.t, rec)) { hit = true; best = i; }
+            if (hit_sphere(c, 0.2f, moving, r, tmin, rec.t, rec)) { hit = true; best = i; }
         }
     }
     if (best >= 0) rec.m = small_sphere_material(tab[best].cls, tab[best].seed);
@@ -276,14 +294,14 @@ __device__ __forceinline__ bool scatter(float& gSeed, const Ray& in, const Rec& 
 }
 
 // directlighting, PT/P3D_RT.glsl:182-232
-__device__ __forceinline__ f3 direct_lighting(const SmallSphere* tab, int* wave_union, float& gSeed, f3 lpos, const Ray& r, const Rec& rec) {
+__device__ __forceinline__ f3 direct_lighting(const SmallSphere* tab, const SphereSets& sets, int* wave_union, float& gSeed, f3 lpos, const Ray& r, const Rec& rec) {
     f3 lightDir = norm3(lpos - rec.pos);
     const float dotRec = fmaxf(dot3(rec.normal, lightDir), 0.0f);
     if (!(dotRec > 0.0f)) return F3(0, 0, 0);
     Ray feeler; feeler.o = rec.pos + PT_EPS * rec.normal; feeler.d = lightDir; feeler.t = 0.0f;
     const float size = len3(lightDir);          // (sic) length of the normalised direction
     Rec dummy;
-    if (hit_world(tab, wave_union, gSeed, feeler, 0.0f, size, dummy)) return F3(0, 0, 0);
+    if (hit_world(tab, sets, wave_union, gSeed, feeler, 0.0f, size, dummy)) return F3(0, 0, 0);
     f3 specCol, diffCol; float shininess, diffuse, specular;
     if (rec.m.type == MT_DIFFUSE) { specCol = F3(0.1f, 0.1f, 0.1f); diffCol = rec.m.albedo; shininess = 10.0f; diffuse = 1.0f; specular = 0.0f; }
     else if (rec.m.type == MT_METAL) { specCol = rec.m.albedo; diffCol = F3(0, 0, 0); shininess = 100.0f; diffuse = 0.0f; specular = 1.0f; }
@@ -296,15 +314,15 @@ __device__ __forceinline__ f3 direct_lighting(const SmallSphere* tab, int* wave_
 }
 
 // rayColor, PT/P3D_RT.glsl:234-282 (MAX_BOUNCES 10, RUSSIAN_ROULETTE false)
-__device__ __forceinline__ f3 ray_color(const SmallSphere* tab, int* wave_union, float& gSeed, Ray r) {
+__device__ __forceinline__ f3 ray_color(const SmallSphere* tab, const SphereSets& sets, int* wave_union, float& gSeed, Ray r) {
     Rec rec;
     rec.pos = F3(0, 0, 0); rec.normal = F3(0, 0, 0); rec.t = 0.0f; rec.m = diffuse_mat(F3(0, 0, 0));
     f3 col = F3(0, 0, 0), thr = F3(1, 1, 1);
     for (int i = 0; i < 10; ++i) {
-        if (hit_world(tab, wave_union, gSeed, r, 0.001f, 10000.0f, rec)) {
-            col = col + direct_lighting(tab, wave_union, gSeed, F3(-10.0f, 15.0f, 0.0f), r, rec) * thr;
-            col = col + direct_lighting(tab, wave_union, gSeed, F3(8.0f, 15.0f, 3.0f), r, rec) * thr;
-            col = col + direct_lighting(tab, wave_union, gSeed, F3(1.0f, 15.0f, -9.0f), r, rec) * thr;
+        if (hit_world(tab, sets, wave_union, gSeed, r, 0.001f, 10000.0f, rec)) {
+            col = col + direct_lighting(tab, sets, wave_union, gSeed, F3(-10.0f, 15.0f, 0.0f), r, rec) * thr;
+            col = col + direct_lighting(tab, sets, wave_union, gSeed, F3(8.0f, 15.0f, 3.0f), r, rec) * thr;
+            col = col + direct_lighting(tab, sets, wave_union, gSeed, F3(1.0f, 15.0f, -9.0f), r, rec) * thr;
             Ray sr; f3 atten;
             if (scatter(gSeed, r, rec, atten, sr)) { r = sr; thr = thr * atten; }
         } else {
@@ -336,6 +354,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
     __shared__ int wave_union[4];          // cell range union scratch of this wave (hit_world)
     build_small_spheres(tab);
     __syncthreads();
+    SphereSets sets;
+    {   // lane i looks at cells i and 64 + i; ballots make the sets wave-uniform
+        const int lane = (int)threadIdx.x;
+        const int c0 = tab[lane].cls, c1 = lane < 36 ? tab[64 + lane].cls : -1;
+        sets.present_lo = __ballot(c0 >= 0); sets.present_hi = __ballot(c1 >= 0);
+        sets.moving_lo = __ballot(c0 == 0); sets.moving_hi = __ballot(c1 == 0);
+    }
     const int tiles_x = (P.ires_x + 15) / 16;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int x = tx * 16 + (threadIdx.x & 15), y = ty * 4 + (threadIdx.x >> 4);
@@ -360,7 +385,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         r.o = P.cam.eye + P.cam.u * lsx + P.cam.v * lsy;
         r.d = norm3(P.cam.u * (ppx - lsx) + P.cam.v * (ppy - lsy) + P.cam.n * (-P.cam.focusDist * P.cam.planeDist));
         r.t = time;
-        f3 color = ray_color(tab, wave_union, gSeed, r);
+        f3 color = ray_color(tab, sets, wave_union, gSeed, r);
         sum = sum + color;
         // accumulation, PT/P3D_RT.glsl:345-365
         const f3 prevLinear = pow3(F3(prev0, prev1, prev2), 2.2f);
