@@ -113,3 +113,22 @@ def test_cull_never_hit_is_invisible_in_the_output():
     assert ds.stats()["n_culled"] == 0
     ds.render(hs.camera(), accel=0)
     ds.close()
+
+
+def test_large_synthetic_frame_against_the_reference_bvh(tmp_path):
+    """1e5 primitives at 960x540: too many for the reference's brute-force closest hit, so the
+    oracle runs with the fall-through removed -- its restatement of the reference's own BVH::Traverse decides
+    the hits.  That differs from brute force only where a hit point lands exactly on a box face, so all but a
+    few pixels must agree, and those that do must agree in colour as usual."""
+    n, res = 100000, (960, 540)
+    path = S.write_p3f(str(tmp_path / "synthetic.p3f"), n, *res)
+    ref = O.Scene(path).render(max_depth=4, accel=2, threads=16, break_fixed=1)
+    hs = P.HostScene(path)
+    ds = P.DeviceScene.from_host(hs)
+    out = ds.render(hs.camera(), max_depth=4, accel=2, counters=True)
+    ds.close()
+    same = out["hit_id"] == ref["hit_id"]
+    assert same.mean() >= 0.9999, "primary hits differ in %d px" % int((~same).sum())
+    d = np.abs(out["rgb32f"] - ref["rgb32f"]).max(axis=2)
+    assert (d <= 1e-4).mean() >= 0.999
+    assert abs(out["counters"]["rays"] - ref["counters"]["rays"]) <= 1e-3 * ref["counters"]["rays"]
