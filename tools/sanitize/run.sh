@@ -1,0 +1,16 @@
+#!/bin/bash
+# AddressSanitizer + UBSan over the CPU-side code (GPU sanitizers are not available on the pool):
+# the host layer (.p3f loader, flattening, SAH builder, sample stream, PNG writer) and the oracle,
+# on every golden scene plus malformed input.  Run from the repository root; needs no GPU.
+set -e
+R=$(pwd); W=/tmp/p3d_san; mkdir -p $W
+for f in $R/tests/golden/scenes/*.p3f.xz; do xz -dkc $f > $W/$(basename $f .xz); done
+C=$R/u_4a_2s_p3d_raytracer_template2_amd/csrc
+SAN="-g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off"
+g++ $SAN -std=c++17 -I$C -I$R/include $R/tools/sanitize/host_main.cpp $C/host/p3d_scene.cpp $C/bvh_builder.cpp \
+    $C/scene_flatten.cpp -o $W/san_host -Wl,--unresolved-symbols=ignore-all
+g++ $SAN -std=c++14 -I$R/oracle $R/tools/sanitize/oracle_main.cpp $R/oracle/p3d_oracle.cpp $R/oracle/pt_oracle.cpp -lpthread -o $W/san_oracle
+cd $W
+./san_host *.p3f
+./san_oracle balls_box.p3f balls_low.p3f balls_medium.p3f dof.p3f mount_high.p3f mount_low.p3f
+echo "sanitizers: clean"
