@@ -204,3 +204,27 @@ def test_png_writer_round_trip(tmp_path):
     raw = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(37, 1 + 211 * 3)
     assert (raw[:, 0] == 0).all()
     assert np.array_equal(raw[:, 1:].reshape(37, 211, 3), img[::-1])
+
+
+def test_synthetic_scene_text_and_array_forms_agree(tmp_path):
+    """The scaling scene of SURVEY section 8d: the .p3f the oracle reads and the arrays bench.py uploads
+    describe the same primitives, materials and lights, and the host BVH over it is well formed."""
+    from u_4a_2s_p3d_raytracer_template2_amd import synthetic as S
+    n = 3000
+    path = S.write_p3f(str(tmp_path / "synthetic.p3f"), n, 64, 48)
+    ptype, data, material, mats, lights, bg = S.arrays(n)
+    hs = P.HostScene(path)
+    arr = hs.arrays()
+    assert np.array_equal(arr[0], ptype)
+    d = np.asarray(arr[1]).reshape(-1, 12)
+    sph = ptype == 0
+    assert np.array_equal(d[sph, :4], data[sph, :4]) and np.array_equal(d[~sph, :9], data[~sph, :9])
+    m = np.asarray(arr[3]).reshape(-1, 12)
+    assert np.array_equal(m[np.asarray(arr[2])], mats[material])
+    assert np.array_equal(np.asarray(arr[4]).reshape(-1, 6), lights)
+    sc = O.Scene(path)
+    assert sc.n_prims == n
+    desc, keep = api.make_desc(ptype, data, material, mats, lights, bg)
+    bvh = api.host_bvh(desc)
+    assert bvh["n_prims"] == n and len(bvh["refs"]) == n and bvh["max_depth"] <= 40
+    assert sorted((bvh["refs"] & 0x3FFFFFFF).tolist()) == sorted(list(range(n // 2)) * 2)   # every sphere and triangle once
