@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Render a few frames of one scene (name of a golden .p3f, or N = primitives of the synthetic scaling
 scene) with one schedule: wavefront | tree | default.  For rocprofv3 runs.
-usage: render_frames.py SCENE SCHEDULE [FRAMES]"""
+usage: render_frames.py SCENE SCHEDULE [FRAMES [W H [DEPTH]]]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -11,7 +11,8 @@ import u_4a_2s_p3d_raytracer_template2_amd as P
 from u_4a_2s_p3d_raytracer_template2_amd import synthetic as S, api
 arg, sched = sys.argv[1], sys.argv[2]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-res = (1920, 1080)
+res = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (1920, 1080)
+depth = int(sys.argv[6]) if len(sys.argv) > 6 else 4
 if arg.isdigit():
     cam = P.HostScene(S.camera_p3f("/tmp/synth_camera.p3f", *res)).camera()
     desc, keep = api.make_desc(*S.arrays(int(arg)))
@@ -22,6 +23,6 @@ else:
 buf = torch.zeros((res[1] + 16, res[0], 3), dtype=torch.uint8, device="cuda")
 kw = {"wavefront": dict(wavefront=True), "tree": dict(tree=True), "default": {}}[sched]
 for _ in range(n):
-    ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=4, **kw)
+    ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=depth, **kw)
 ds.sync()
 print(ds.last_schedule())
