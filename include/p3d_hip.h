@@ -204,7 +204,7 @@ int p3d_get_counters(p3d_scene* scene, p3d_counters* out);
 /* Launch tuning that never changes results (0 keeps the current value): xcd_chunk =
  * consecutive 16x4-pixel tiles given to one XCD before moving to the next (1 = round robin,
  * best load balance; larger = more L2 locality per XCD for big scenes); workspace_mib = HBM
- * budget for the wavefront ray queues (default 65536; frames that need more run in bands);
+ * budget for the wavefront ray queues (default 65536, shared by the concurrent sample passes of a frame; frames that need more run in bands);
  * waves_per_simd = register budget of the ray kernels expressed as resident waves per SIMD:
  * 0 compiler default, 5 / 6 trade spilled registers for latency hiding, -1 keeps. */
 int p3d_set_tuning(p3d_scene* scene, int32_t xcd_chunk, int32_t workspace_mib, int32_t waves_per_simd);

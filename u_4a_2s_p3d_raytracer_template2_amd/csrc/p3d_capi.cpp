@@ -26,6 +26,7 @@ hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, bool
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream);
 hipError_t launch_raygen_table(float* fx, float* fy, int res_x, int res_y, hipStream_t stream);
 hipError_t prepare_kernels(size_t max_lds);
+hipError_t launch_sum_samples(const LaunchParams& P, size_t first_px, size_t n_px, hipStream_t stream);
 hipError_t launch_deinterleave(const void* gathered, void* frame, int res_x, int res_y, int row_block,
                                int world, size_t rank_stride, int bpp, hipStream_t stream);
 hipError_t build_lbvh_device(const std::vector<BuildPrim>& prims, const BvhOptions& opt, NodePair* d_nodes,
@@ -51,6 +52,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU
 constexpr int kMaxDepth = 16;
+constexpr int kLanes = 4;                             // concurrent sample passes of one frame
 constexpr unsigned kPersistentWaves = 256 * 16;       // deeper-level launches of LDS-resident scenes (full waves)
 constexpr unsigned kPersistentWavesNarrow = 256 * 16 * 4;   // ... of HBM-resident scenes (narrow waves, 4 per SIMD)
 
@@ -108,8 +110,22 @@ struct p3d_scene {
     RawBuf fb_rgb8, fb_rgb32f, fb_hit, samples;
     RawBuf ray_tab; int tab_res_x = 0, tab_res_y = 0;   // cached per-column / per-row ray factors
     // wavefront workspace: ray queues (levels 2..D), parked nodes (levels 1..D-1), counters
-    RawBuf wf_rays[kMaxDepth + 2], wf_nodes[kMaxDepth + 2], wf_counts, wf_accum;
-    RawBuf wf_rng[kMaxDepth + 2];            // random-stream keys of the queued rays (stochastic features)
+    // Wavefront workspaces.  A frame of several sample passes (spp > 0) runs up to kLanes passes at a
+    // time, each on its own stream with its own queues: the latency-bound deep levels and launch tails
+    // of one pass fill with another pass's work, like independent frames do.  Lane 0 is the scene's stream.
+    struct Workspace {
+        RawBuf rays[kMaxDepth + 2], nodes[kMaxDepth + 2], counts;
+        RawBuf rng[kMaxDepth + 2];           // random-stream keys of the queued rays (stochastic features)
+        void release() {
+            for (auto& b : rays) b.release();
+            for (auto& b : nodes) b.release();
+            for (auto& b : rng) b.release();
+            counts.release();
+        }
+    } ws[kLanes];
+    RawBuf wf_planes;                        // [sample][local px][3] clamped sample colours (spp > 0)
+    hipStream_t lane_stream[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     // worst-case queues a frame may allocate; only what a frame needs is ever allocated.  64 GiB holds
     // BASELINE config 4 (4096^2, depth 6: 58 GB worst case) in one band: 10.7 -> 9.3 ms against 8 GiB.
     size_t workspace_budget = (size_t)64 << 30;
@@ -226,6 +242,11 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     if ((e = hipEventCreate(&s->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     for (auto& ev : s->ev_prof) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
     for (auto& ev : s->ev_pick) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    for (int i = 1; i < kLanes; i++) {
+        if ((e = hipStreamCreateWithFlags(&s->lane_stream[i], hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+        if ((e = hipEventCreateWithFlags(&s->ev_join[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    }
     {   // pack the per-lane-indexed arrays into one blob of 16-byte quads
         std::vector<uint32_t> blob;
         auto section = [&](const void* data, size_t bytes) {
@@ -277,10 +298,13 @@ int p3d_scene_destroy(p3d_scene* s) {
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     s->blob.release(); s->planes.release(); s->plane_meta.release(); s->lights.release(); s->soft_lights.release();
     s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release(); s->ray_tab.release();
-    for (auto& b : s->wf_rays) b.release();
-    for (auto& b : s->wf_nodes) b.release();
-    s->wf_counts.release(); s->wf_accum.release();
-    for (auto& b : s->wf_rng) b.release();
+    for (auto& w : s->ws) w.release();
+    s->wf_planes.release();
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    for (int i = 1; i < kLanes; i++) {
+        if (s->ev_join[i]) (void)hipEventDestroy(s->ev_join[i]);
+        if (s->lane_stream[i]) { (void)hipStreamSynchronize(s->lane_stream[i]); (void)hipStreamDestroy(s->lane_stream[i]); }
+    }
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -333,13 +357,14 @@ constexpr int kShards = 64;   // queue shards (power of two); spreads the slot-a
 // One sample pass over one band of tile rows, level by level (see p3d_kernels.hip).
 // shard_px = pixels a shard can own in this band (worst case), so level l holds at most
 // shard_px << (l-1) rays / nodes per shard.
-int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, bool lds, bool packet, size_t shard_px, bool profile) {
+int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t stream, LaunchParams P, bool count, bool lds,
+                       bool packet, size_t shard_px, bool profile) {
     const int D = P.max_depth;
-    uint32_t* counts = (uint32_t*)s->wf_counts.p;      // [level][shard] ray counts, then node counts
+    uint32_t* counts = (uint32_t*)ws.counts.p;         // [level][shard] ray counts, then node counts
     const size_t n_counts = (size_t)2 * (kMaxDepth + 2) * kShards;
-    HIP_TRY(hipMemsetAsync(counts, 0, n_counts * sizeof(uint32_t), s->stream));
-    auto rays = [&](int l) { return (l >= 2 && l <= D) ? (RayRec*)s->wf_rays[l].p : nullptr; };
-    auto nodes = [&](int l) { return (l >= 1 && l <= D - 1) ? (NodeRec*)s->wf_nodes[l].p : nullptr; };
+    HIP_TRY(hipMemsetAsync(counts, 0, n_counts * sizeof(uint32_t), stream));
+    auto rays = [&](int l) { return (l >= 2 && l <= D) ? (RayRec*)ws.rays[l].p : nullptr; };
+    auto nodes = [&](int l) { return (l >= 1 && l <= D - 1) ? (NodeRec*)ws.nodes[l].p : nullptr; };
     auto qcount = [&](int l) { return counts + (size_t)l * kShards; };
     auto ncount = [&](int l) { return counts + (size_t)(kMaxDepth + 2 + l) * kShards; };
     auto cap = [&](int l) { return (uint32_t)(shard_px << (l - 1)); };
@@ -347,13 +372,13 @@ int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, bool lds, bool 
     P.wf_level = 1;
     P.wf_rays_in = nullptr; P.wf_count_in = nullptr; P.wf_cap_in = 0;
     P.wf_rays_out = rays(2); P.wf_count_out = qcount(2); P.wf_cap_out = cap(2);
-    auto rng = [&](int l) { return (P.features && l >= 2 && l <= D) ? (uint32_t*)s->wf_rng[l].p : nullptr; };
+    auto rng = [&](int l) { return (P.features && l >= 2 && l <= D) ? (uint32_t*)ws.rng[l].p : nullptr; };
     P.wf_rng_in = nullptr; P.wf_rng_out = rng(2);
     P.wf_nodes_parent = nullptr; P.wf_ncap_parent = 0;
     P.wf_nodes_self = nodes(1); P.wf_ncount_self = ncount(1); P.wf_ncap_self = cap(1);
-    if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
-    HIP_TRY(launch_wf_primary(P, count, lds, packet, s->occupancy, s->stream));
-    if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream));
+    if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], stream));
+    HIP_TRY(launch_wf_primary(P, count, lds, packet, s->occupancy, stream));
+    if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], stream));
     for (int l = 2; l <= D; l++) {
         P.wf_level = l;
         P.wf_rays_in = rays(l); P.wf_count_in = qcount(l); P.wf_cap_in = cap(l);
@@ -364,13 +389,13 @@ int run_wavefront_pass(p3d_scene* s, LaunchParams P, bool count, bool lds, bool 
         size_t total = (size_t)cap(l) * kShards;
         unsigned waves = (unsigned)std::min<size_t>((total + 63) / 64, lds ? kPersistentWaves : kPersistentWavesNarrow);
         waves = std::max<unsigned>(kShards * 4, (waves / (kShards * 4)) * (kShards * 4));   // whole workgroups per shard
-        HIP_TRY(launch_wf_secondary(P, count, lds, packet, s->occupancy, waves, s->stream));
+        HIP_TRY(launch_wf_secondary(P, count, lds, packet, s->occupancy, waves, stream));
     }
     for (int l = D - 1; l >= 1; l--) {
         P.wf_level = l;
         P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
         P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = l > 1 ? cap(l - 1) : 0;
-        HIP_TRY(launch_wf_resolve(P, kShards * 4, s->stream));
+        HIP_TRY(launch_wf_resolve(P, kShards * 4, stream));
     }
     return P3D_OK;
 }
@@ -496,9 +521,11 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     }
     // wavefront bands: worst-case queues for a band of tile rows must fit the workspace budget
     const size_t tile_row_px = (size_t)P.tiles_x * 64 * P.wg_waves;
-    size_t wf_bpp = wavefront_bytes_per_pixel(prm->max_depth) + (prm->spp > 0 ? 12 : 0);
+    // sample passes of one frame run on up to kLanes streams, each with its share of the budget
+    const int lanes = prm->spp > 0 ? std::min(kLanes, prm->spp * prm->spp) : 1;
+    size_t wf_bpp = wavefront_bytes_per_pixel(prm->max_depth);
     if (stochastic) for (int l = 2; l <= prm->max_depth; l++) wf_bpp += ((size_t)1 << (l - 1)) * sizeof(uint32_t);
-    size_t band_tile_rows = wf_bpp ? s->workspace_budget / (wf_bpp * tile_row_px) : (size_t)P.tiles_y;
+    size_t band_tile_rows = wf_bpp ? s->workspace_budget / lanes / (wf_bpp * tile_row_px) : (size_t)P.tiles_y;
     if (wf_bpp == 0) band_tile_rows = (size_t)P.tiles_y;
     band_tile_rows = std::min<size_t>(band_tile_rows, (size_t)P.tiles_y);
     const bool use_tree = tree_requested || band_tile_rows == 0;
@@ -544,16 +571,27 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         // a shard owns every kShards-th tile of the band
         const size_t band_tiles = band_tile_rows * (size_t)P.tiles_x;
         const size_t shard_px = ((band_tiles + kShards - 1) / kShards) * 64 * P.wg_waves;
-        for (int l = 2; l <= D; l++) HIP_TRY(s->wf_rays[l].ensure((shard_px << (l - 1)) * kShards * sizeof(RayRec)));
-        for (int l = 1; l <= D - 1; l++) HIP_TRY(s->wf_nodes[l].ensure((shard_px << (l - 1)) * kShards * sizeof(NodeRec)));
-        HIP_TRY(s->wf_counts.ensure((size_t)2 * (kMaxDepth + 2) * kShards * sizeof(uint32_t)));
-        if (stochastic)
-            for (int l = 2; l <= D; l++) HIP_TRY(s->wf_rng[l].ensure((shard_px << (l - 1)) * kShards * sizeof(uint32_t)));
-        if (prm->spp > 0) { HIP_TRY(s->wf_accum.ensure(npx * 12)); P.wf_accum = (float*)s->wf_accum.p; }
+        for (int ln = 0; ln < lanes; ln++) {
+            p3d_scene::Workspace& w = s->ws[ln];
+            for (int l = 2; l <= D; l++) HIP_TRY(w.rays[l].ensure((shard_px << (l - 1)) * kShards * sizeof(RayRec)));
+            for (int l = 1; l <= D - 1; l++) HIP_TRY(w.nodes[l].ensure((shard_px << (l - 1)) * kShards * sizeof(NodeRec)));
+            HIP_TRY(w.counts.ensure((size_t)2 * (kMaxDepth + 2) * kShards * sizeof(uint32_t)));
+            if (stochastic)
+                for (int l = 2; l <= D; l++) HIP_TRY(w.rng[l].ensure((shard_px << (l - 1)) * kShards * sizeof(uint32_t)));
+        }
+        if (prm->spp > 0) {
+            HIP_TRY(s->wf_planes.ensure((size_t)P.wf_nsamples * npx * 12));
+            P.wf_planes = (float*)s->wf_planes.p; P.wf_plane_stride = (uint64_t)npx * 3;
+        }
         if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));   // after the (host-side) allocations
-        // samples outermost: a pixel's clamped sample colours are summed in sample order
+        if (lanes > 1) {                                   // the other lanes start after what the stream holds
+            HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
+            for (int ln = 1; ln < lanes; ln++) HIP_TRY(hipStreamWaitEvent(s->lane_stream[ln], s->ev_fork, 0));
+        }
         for (int smp = 0; smp < P.wf_nsamples; smp++) {
             P.wf_sample = smp;
+            const int ln = smp % lanes;
+            const hipStream_t lane_stream = ln == 0 ? s->stream : s->lane_stream[ln];
             for (size_t r0 = 0; r0 < (size_t)P.tiles_y; r0 += band_tile_rows) {
                 LaunchParams B = P;
                 B.wf_tile_row0 = (int32_t)r0;
@@ -561,10 +599,17 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
                 B.n_tiles = B.tiles_x * B.wf_tile_rows;
                 int chunks = (B.n_tiles + B.xcd_chunk - 1) / B.xcd_chunk;
                 B.grid_blocks = ((chunks + 7) / 8) * 8 * B.xcd_chunk;
-                int rc = run_wavefront_pass(s, B, count, lds_scene, packet, shard_px, profile && smp == 0 && r0 == 0);
+                int rc = run_wavefront_pass(s, s->ws[ln], lane_stream, B, count, lds_scene, packet, shard_px,
+                                            profile && smp == 0 && r0 == 0);
                 if (rc) return rc;
             }
         }
+        for (int ln = 1; ln < lanes; ln++) {               // ... and the stream continues after all of them
+            HIP_TRY(hipEventRecord(s->ev_join[ln], s->lane_stream[ln]));
+            HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join[ln], 0));
+        }
+        // a pixel's clamped sample colours are summed in sample order, then divided by 16
+        if (prm->spp > 0) HIP_TRY(launch_sum_samples(P, 0, npx, s->stream));
     }
     if (profile) { HIP_TRY(hipEventRecord(s->ev_prof[1], s->stream)); s->profile_valid = true; }
     if (measuring >= 0) {

@@ -98,7 +98,7 @@ struct LaunchParams {
     RayRec* wf_rays_out;       uint32_t* wf_count_out;           // level wf_level + 1 queue
     NodeRec* wf_nodes_parent;                                     // level wf_level - 1 nodes
     NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
-    float* wf_accum;                                              // [local px][3] running sample sum
+    float* wf_planes; uint64_t wf_plane_stride;                   // [sample][local px][3] clamped sample colours; floats per plane
     int32_t wf_min_width;            // fewest lanes a deeper-level wave may use (64 = never narrow)
     // distribution-ray-tracing features with random draws (p3d_shade.h): feature bits, frame seed, and
     // the random-stream key of every queued ray ([shard][cap] like the ray queues; nullptr when off)

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "p3d_device_types.h"
 #include "p3d_shade.h"
 
@@ -57,16 +59,26 @@ __device__ __forceinline__ void write_pixel(const LaunchParams& P, size_t p, V3 
 
 // One finished primary-ray tree: "rayTracing(...).clamp()", summed over samples and divided
 // by 4*4 in the anti-aliased path (RT/main.cpp:774,797-800).
+// In the anti-aliased path every sample pass writes its clamped colours to its own plane (so that the
+// passes of a frame can run concurrently) and sum_samples_kernel adds the planes in sample order.
 __device__ __forceinline__ void sink_sample(const LaunchParams& P, size_t p, V3 ret) {
     V3 c = clampc(ret);
     if (P.wf_nsamples <= 1 && P.spp == 0) { write_pixel(P, p, c); return; }
-    float* a = P.wf_accum + 3 * p;
-    V3 acc = (P.wf_sample == 0) ? mk(0.0f, 0.0f, 0.0f) : mk(a[0], a[1], a[2]);
-    acc = add(acc, c);
-    if (P.wf_sample + 1 == P.wf_nsamples) {
+    float* a = P.wf_planes + (size_t)P.wf_sample * P.wf_plane_stride + 3 * p;
+    a[0] = c.x; a[1] = c.y; a[2] = c.z;
+}
+
+// "color += rayTracing(...).clamp()" over the samples in order, then "color / (4 * 4)"
+// (RT/main.cpp:797-800), for the rows [row0, row0 + rows) of the compact buffer
+__global__ __launch_bounds__(256) void sum_samples_kernel(const LaunchParams P, size_t first_px, size_t n_px) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_px; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = first_px + i;
+        V3 acc = mk(0.0f, 0.0f, 0.0f);
+        for (int smp = 0; smp < P.wf_nsamples; smp++) {
+            const float* a = P.wf_planes + (size_t)smp * P.wf_plane_stride + 3 * p;
+            acc = add(acc, mk(a[0], a[1], a[2]));
+        }
         write_pixel(P, p, mk(fdiv(acc.x, 16.0f), fdiv(acc.y, 16.0f), fdiv(acc.z, 16.0f)));
-    } else {
-        a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
     }
 }
 
@@ -588,6 +600,12 @@ hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, bool
 }
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream) {
     hipLaunchKernelGGL(wf_resolve_kernel, dim3(blocks), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_samples(const LaunchParams& P, size_t first_px, size_t n_px, hipStream_t stream) {
+    const unsigned blocks = (unsigned)std::min<size_t>((n_px + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(sum_samples_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, P, first_px, n_px);
     return hipGetLastError();
 }
 
