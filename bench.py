@@ -338,10 +338,9 @@ def main():
                     gathered.copy_(hg)
             else:
                 MG.gather_to_root(tiles, dist, rank, world, gathered)
-            if rank == 0:
-                for f in range(B):
-                    ds.deinterleave(gathered[0, f].data_ptr(), frames[f].data_ptr(), W, H, ROW_BLOCK, world, 3,
-                                    rank_stride_bytes=B * tile_bytes)
+            if rank == 0:                               # all B frames of the step in one launch
+                ds.deinterleave_frames(gathered.data_ptr(), frames.data_ptr(), W, H, ROW_BLOCK, world, 3, B,
+                                       rank_stride_bytes=B * tile_bytes, tile_stride_bytes=tile_bytes)
 
     def barrier():
         if world > 1:

@@ -235,6 +235,13 @@ int p3d_timer_end(p3d_scene* scene, float* elapsed_ms);
 int p3d_deinterleave(p3d_scene* scene, const void* gathered, void* frame, int32_t res_x,
                      int32_t res_y, int32_t row_block, int32_t world, int32_t bytes_per_pixel,
                      uint64_t rank_stride_bytes);
+/* The same for a batch of n_frames frames in ONE launch: frame f of rank r starts at
+ * gathered + r * rank_stride_bytes + f * tile_stride_bytes (0 = one compact tile buffer; rank stride 0 =
+ * n_frames tile buffers back to back) and is written to frames + f * frame_stride_bytes (0 = frames
+ * back to back). Rows and strides that are multiples of 16 bytes are moved 16 bytes at a time. */
+int p3d_deinterleave_frames(p3d_scene* scene, const void* gathered, void* frames, int32_t res_x, int32_t res_y,
+                            int32_t row_block, int32_t world, int32_t bytes_per_pixel, uint64_t rank_stride_bytes,
+                            int32_t n_frames, uint64_t tile_stride_bytes, uint64_t frame_stride_bytes);
 
 /* Diagnostic: with a device buffer of (tiles x waves-per-workgroup x 8) uint64 set here, the
  * level-1 kernel writes per-wave 100 MHz timestamps (tile start, after ray generation, after the

@@ -224,3 +224,36 @@ def test_error_behaviour():
     ds.close()
     with pytest.raises(P.P3DError):
         P.DeviceScene.from_host(hs, device=99)
+
+
+@pytest.mark.parametrize("width", [64, 50])      # 192-byte rows take the 16-byte path, 150-byte rows the byte path
+def test_deinterleave_kernels_restore_the_frame(width):
+    """Rank-0 side of SURVEY 8e on the device: compact per-rank tile buffers of a batch of frames ->
+    full bottom-up frames, one launch (p3d_deinterleave_frames) or one per frame (p3d_deinterleave)."""
+    import torch
+    from u_4a_2s_p3d_raytracer_template2_amd import multigpu as MG
+    hs = P.HostScene(scene_path("balls_low"))
+    H, world, B, rb = 72, 3, 2, 16
+    hs.set_resolution(width, H)
+    cam = hs.camera()
+    ds = P.DeviceScene.from_host(hs)
+    rows = MG.padded_rows(H, rb, world)
+    full = [ds.render(cam, max_depth=2 + f, accel=2, spp=0) for f in range(B)]
+    gathered = torch.zeros((world, B, rows, width, 3), dtype=torch.uint8, device="cuda")
+    for r in range(world):
+        for f in range(B):
+            ds.render_device(cam, rgb8_ptr=gathered[r, f].data_ptr(), max_depth=2 + f, accel=2, spp=0,
+                             rank=r, world=world, row_block=rb)
+    ds.sync()
+    tile = rows * width * 3
+    frames = torch.zeros((B, H, width, 3), dtype=torch.uint8, device="cuda")
+    ds.deinterleave_frames(gathered.data_ptr(), frames.data_ptr(), width, H, rb, world, 3, B,
+                           rank_stride_bytes=B * tile, tile_stride_bytes=tile)
+    ds.sync()
+    single = torch.zeros((H, width, 3), dtype=torch.uint8, device="cuda")
+    for f in range(B):
+        assert np.array_equal(frames[f].cpu().numpy(), full[f]["rgb8"])
+        ds.deinterleave(gathered[0, f].data_ptr(), single.data_ptr(), width, H, rb, world, 3, rank_stride_bytes=B * tile)
+        ds.sync()
+        assert np.array_equal(single.cpu().numpy(), full[f]["rgb8"])
+    ds.close()

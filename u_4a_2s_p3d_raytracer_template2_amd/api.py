@@ -77,7 +77,7 @@ class SceneStats(C.Structure):
 # every symbol include/p3d_hip.h declares (tests check that the library exports them all)
 C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_scene_create",
                  "p3d_scene_destroy", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
-                 "p3d_get_counters", "p3d_get_profile", "p3d_last_schedule", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end",
+                 "p3d_get_counters", "p3d_get_profile", "p3d_last_schedule", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end", "p3d_deinterleave_frames",
                  "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_set_stamps"]
 
 
@@ -379,6 +379,15 @@ class DeviceScene:
         p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile, wavefront, soft_shadow, fuzzy_reflection, seed)
         o = Outputs(rgb8_ptr or None, rgb32f_ptr or None, hit_ptr or None, 1)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
+
+    def deinterleave_frames(self, gathered_ptr, frames_ptr, res_x, res_y, row_block, world, bpp, n_frames,
+                            rank_stride_bytes=0, tile_stride_bytes=0, frame_stride_bytes=0):
+        L = lib()
+        L.p3d_deinterleave_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_int32, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64]
+        _check(L.p3d_deinterleave_frames(self.h, C.c_void_p(gathered_ptr), C.c_void_p(frames_ptr), res_x, res_y, row_block,
+                                         world, bpp, int(rank_stride_bytes), int(n_frames), int(tile_stride_bytes),
+                                         int(frame_stride_bytes)), "p3d_deinterleave_frames")
 
     def deinterleave(self, gathered_ptr, frame_ptr, res_x, res_y, row_block, world, bpp, rank_stride_bytes=0):
         _check(lib().p3d_deinterleave(self.h, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), res_x, res_y,

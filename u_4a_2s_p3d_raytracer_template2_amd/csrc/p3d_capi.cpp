@@ -27,8 +27,9 @@ hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t
 hipError_t launch_raygen_table(float* fx, float* fy, int res_x, int res_y, hipStream_t stream);
 hipError_t prepare_kernels(size_t max_lds);
 hipError_t launch_sum_samples(const LaunchParams& P, size_t first_px, size_t n_px, hipStream_t stream);
-hipError_t launch_deinterleave(const void* gathered, void* frame, int res_x, int res_y, int row_block,
-                               int world, size_t rank_stride, int bpp, hipStream_t stream);
+hipError_t launch_deinterleave(const void* gathered, void* frames, int res_x, int res_y, int row_block,
+                               int world, size_t rank_stride, int bpp, int n_frames, size_t in_stride,
+                               size_t out_stride, hipStream_t stream);
 hipError_t build_lbvh_device(const std::vector<BuildPrim>& prims, const BvhOptions& opt, NodePair* d_nodes,
                              uint32_t* d_refs, BvhStats& stats, hipStream_t stream);
 hipError_t launch_debug_intersect(uint32_t n, const uint32_t* type, const float* prim12, const float* origin,
@@ -691,17 +692,26 @@ int p3d_timer_end(p3d_scene* s, float* ms) {
     return P3D_OK;
 }
 
-int p3d_deinterleave(p3d_scene* s, const void* gathered, void* frame, int32_t res_x, int32_t res_y,
-                     int32_t row_block, int32_t world, int32_t bpp, uint64_t rank_stride_bytes) {
-    if (!s || !gathered || !frame) return fail(P3D_ERR_ARG, "NULL argument");
-    if (res_x <= 0 || res_y <= 0 || world <= 0) return fail(P3D_ERR_ARG, "bad sizes");
+int p3d_deinterleave_frames(p3d_scene* s, const void* gathered, void* frames, int32_t res_x, int32_t res_y,
+                            int32_t row_block, int32_t world, int32_t bpp, uint64_t rank_stride_bytes,
+                            int32_t n_frames, uint64_t tile_stride_bytes, uint64_t frame_stride_bytes) {
+    if (!s || !gathered || !frames) return fail(P3D_ERR_ARG, "NULL argument");
+    if (res_x <= 0 || res_y <= 0 || world <= 0 || n_frames <= 0) return fail(P3D_ERR_ARG, "bad sizes");
     if (row_block <= 0) row_block = 16;
     if (bpp != 3 && bpp != 4 && bpp != 12) return fail(P3D_ERR_ARG, "bytes_per_pixel must be 3, 4 or 12");
     HIP_TRY(hipSetDevice(s->device));
-    size_t stride = rank_stride_bytes ? (size_t)rank_stride_bytes
-                                      : (size_t)p3d_local_rows(res_y, row_block, world) * res_x * bpp;
-    HIP_TRY(launch_deinterleave(gathered, frame, res_x, res_y, row_block, world, stride, bpp, s->stream));
+    const size_t tile = (size_t)p3d_local_rows(res_y, row_block, world) * res_x * bpp;
+    const size_t in_stride = tile_stride_bytes ? (size_t)tile_stride_bytes : tile;
+    const size_t stride = rank_stride_bytes ? (size_t)rank_stride_bytes : in_stride * n_frames;
+    const size_t out_stride = frame_stride_bytes ? (size_t)frame_stride_bytes : (size_t)res_y * res_x * bpp;
+    HIP_TRY(launch_deinterleave(gathered, frames, res_x, res_y, row_block, world, stride, bpp, n_frames, in_stride,
+                                out_stride, s->stream));
     return P3D_OK;
+}
+
+int p3d_deinterleave(p3d_scene* s, const void* gathered, void* frame, int32_t res_x, int32_t res_y,
+                     int32_t row_block, int32_t world, int32_t bpp, uint64_t rank_stride_bytes) {
+    return p3d_deinterleave_frames(s, gathered, frame, res_x, res_y, row_block, world, bpp, rank_stride_bytes, 1, 0, 0);
 }
 
 int p3d_debug_intersect(int device, uint32_t n, const uint32_t* type, const float* prim12, const float* origin,

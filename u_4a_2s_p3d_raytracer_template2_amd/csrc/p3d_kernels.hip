@@ -460,18 +460,24 @@ __global__ void raygen_table_kernel(float* fx, float* fy, int res_x, int res_y) 
 }
 
 // ------------------------------------------------------------------ rank-0 de-interleave
-__global__ void deinterleave_kernel(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ frame,
-                                    int res_x, int res_y, int row_block, int world, size_t rank_stride,
-                                    int bpp) {
-    const size_t row_bytes = (size_t)res_x * bpp;
-    const size_t total = row_bytes * res_y;
+// T = uint4 when rows, strides and pointers are 16-byte multiples (1920 x 3 B rows are), else uint8_t.
+// blockIdx.y = frame of a batch (frame f of rank r starts at r * rank_stride + f * in_stride).
+template <class T>
+__global__ void deinterleave_kernel(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ frames,
+                                    size_t row_bytes, int res_y, int row_block, int world, size_t rank_stride,
+                                    size_t in_stride, size_t out_stride) {
+    const size_t row_units = row_bytes / sizeof(T);
+    const size_t total = row_units * res_y;
+    const uint8_t* src = gathered + (size_t)blockIdx.y * in_stride;
+    uint8_t* dst = frames + (size_t)blockIdx.y * out_stride;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
-        size_t y = i / row_bytes, off = i - y * row_bytes;
+        size_t y = i / row_units, off = (i - y * row_units) * sizeof(T);
         int blk = (int)(y / row_block);
         int rank = blk % world, lblk = blk / world;
         size_t lrow = (size_t)lblk * row_block + (y - (size_t)blk * row_block);
-        frame[i] = gathered[(size_t)rank * rank_stride + lrow * row_bytes + off];
+        *reinterpret_cast<T*>(dst + y * row_bytes + off) =
+            *reinterpret_cast<const T*>(src + (size_t)rank * rank_stride + lrow * row_bytes + off);
     }
 }
 
@@ -627,11 +633,20 @@ hipError_t launch_raygen_table(float* fx, float* fy, int res_x, int res_y, hipSt
     hipLaunchKernelGGL(raygen_table_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fx, fy, res_x, res_y);
     return hipGetLastError();
 }
-hipError_t launch_deinterleave(const void* gathered, void* frame, int res_x, int res_y, int row_block,
-                               int world, size_t rank_stride, int bpp, hipStream_t stream) {
-    hipLaunchKernelGGL(deinterleave_kernel, dim3(2048), dim3(256), 0, stream,
-                       (const uint8_t*)gathered, (uint8_t*)frame, res_x, res_y, row_block, world,
-                       rank_stride, bpp);
+hipError_t launch_deinterleave(const void* gathered, void* frames, int res_x, int res_y, int row_block,
+                               int world, size_t rank_stride, int bpp, int n_frames, size_t in_stride,
+                               size_t out_stride, hipStream_t stream) {
+    const size_t row_bytes = (size_t)res_x * bpp;
+    const bool wide = row_bytes % 16 == 0 && rank_stride % 16 == 0 && in_stride % 16 == 0 && out_stride % 16 == 0 &&
+                      (uintptr_t)gathered % 16 == 0 && (uintptr_t)frames % 16 == 0;
+    const size_t units = (wide ? row_bytes / 16 : row_bytes) * (size_t)res_y;
+    const dim3 grid((unsigned)std::min<size_t>((units + 255) / 256, 2048), (unsigned)n_frames);
+    if (wide)
+        hipLaunchKernelGGL(deinterleave_kernel<uint4>, grid, dim3(256), 0, stream, (const uint8_t*)gathered, (uint8_t*)frames,
+                           row_bytes, res_y, row_block, world, rank_stride, in_stride, out_stride);
+    else
+        hipLaunchKernelGGL(deinterleave_kernel<uint8_t>, grid, dim3(256), 0, stream, (const uint8_t*)gathered, (uint8_t*)frames,
+                           row_bytes, res_y, row_block, world, rank_stride, in_stride, out_stride);
     return hipGetLastError();
 }
 
