@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the frames of a step as ONE captured HIP graph instead of ~8 launches per frame "
                          "(auto: use it when capture succeeds)")
+    ap.add_argument("--gather", choices=["pipelined", "sync"], default="pipelined",
+                    help="N > 1: wait for a step's gather (and de-interleave it) while the NEXT step renders into a "
+                         "second tile buffer, or right after the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["config2", "pathtracer", "synthetic"], default="config2",
                     help="config2 = the headline Whitted frame; pathtracer = BASELINE config 5 (P3D_RT.glsl scene, "
@@ -269,11 +272,14 @@ def main():
     B = args.frames_per_step
     rows = H if world == 1 else MG.padded_rows(H, ROW_BLOCK, world)
 
-    # HBM-resident outputs: B compact tile buffers per step (double use: gather source)
-    tiles = torch.zeros((B, rows, W, 3), dtype=torch.uint8, device=dev)
-    gathered = frames = None
+    # HBM-resident outputs: B compact tile buffers per step (double use: gather source).  With the
+    # pipelined gather there are two sets: step i renders into set i % 2 while set (i - 1) % 2 is on the wire.
+    nbuf = 2 if (world > 1 and args.gather == "pipelined") else 1
+    tile_sets = [torch.zeros((B, rows, W, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    tiles = tile_sets[0]
+    gathered_sets = frames = None
     if world > 1 and rank == 0:
-        gathered = torch.zeros((world, B, rows, W, 3), dtype=torch.uint8, device=dev)
+        gathered_sets = [torch.zeros((world, B, rows, W, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         frames = torch.zeros((B, H, W, 3), dtype=torch.uint8, device=dev)
     tile_bytes = rows * W * 3
 
@@ -285,12 +291,12 @@ def main():
     px_local = ctr["pixels"]
     alg_bytes = ctr["algorithmic_bytes"] + 3 * px_local          # + rgb8 written per pixel
 
-    def render_frames(lead):
-        """The B frames of a step: fork the side streams off `lead`, enqueue, join back into `lead`."""
+    def render_frames(lead, buf=0):
+        """The B frames of a step into tile set `buf`: fork the side streams off `lead`, enqueue, join back."""
         for k in range(1, F):
             streams[k].wait_stream(lead)
         for f in range(B):
-            handles[f % F].render_device(cam, rgb8_ptr=tiles[f].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
+            handles[f % F].render_device(cam, rgb8_ptr=tile_sets[buf][f].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
                                          rank=rank, world=world, row_block=ROW_BLOCK, **sched)
         for k in range(1, F):
             lead.wait_stream(streams[k])
@@ -298,7 +304,7 @@ def main():
     # A step is ~8 launches per frame; at a fraction of a millisecond per step the host's launch rate
     # matters, most of all when N GPUs each hold 1/N of the work.  The frames of a step are captured once
     # into a HIP graph (after an eager step has sized every workspace) and replayed with one launch.
-    graph = None
+    graphs = None
     # On one GPU the step is GPU-bound and eager launches measured marginally faster (42.6 vs 40.8 Grays/s),
     # so "auto" captures only when the frame is tiled over several GPUs.
     want_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
@@ -306,16 +312,19 @@ def main():
         try:
             render_frames(main_stream)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            # thread_local: RCCL's watchdog thread may query events while this thread captures
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                lead = torch.cuda.current_stream()
-                handles[0].set_stream(lead.cuda_stream)
-                render_frames(lead)
-            handles[0].set_stream(main_stream.cuda_stream)
-            g.replay()
-            torch.cuda.synchronize()
-            graph = g
+            captured = []
+            for buf in range(nbuf):
+                g = torch.cuda.CUDAGraph()
+                # thread_local: RCCL's watchdog thread may query events while this thread captures
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    lead = torch.cuda.current_stream()
+                    handles[0].set_stream(lead.cuda_stream)
+                    render_frames(lead, buf)
+                handles[0].set_stream(main_stream.cuda_stream)
+                g.replay()
+                torch.cuda.synchronize()
+                captured.append(g)
+            graphs = captured
         except Exception as exc:                     # capture not possible here: keep launching eagerly
             handles[0].set_stream(main_stream.cuda_stream)
             if args.graph == "on":
@@ -323,26 +332,45 @@ def main():
             if rank == 0:
                 print("bench.py: HIP graph capture unavailable (%s); launching eagerly" % exc, file=sys.stderr)
 
+    state = {"next": 0, "pending": None}
+
+    def finish(pending):
+        """Second half of a step: wait for its gather, restore the frames' row order on rank 0."""
+        work, buf, host_gathered = pending
+        work.wait()                                     # RCCL: the current stream waits, the host does not
+        if rank == 0:
+            if host_gathered is not None:
+                gathered_sets[buf].copy_(host_gathered)
+            ds.deinterleave_frames(gathered_sets[buf].data_ptr(), frames.data_ptr(), W, H, ROW_BLOCK, world, 3, B,
+                                   rank_stride_bytes=B * tile_bytes, tile_stride_bytes=tile_bytes)   # one launch
+
     def step():
-        if graph is not None:
-            graph.replay()
+        buf = state["next"]
+        state["next"] = (buf + 1) % nbuf
+        if graphs is not None:
+            graphs[buf].replay()
         else:
-            render_frames(main_stream)
+            render_frames(main_stream, buf)
         if world > 1:
             if rehearsal:
                 torch.cuda.synchronize()
-                host = tiles.cpu()
-                hg = torch.zeros((world,) + tuple(host.shape), dtype=torch.uint8) if rank == 0 else None
-                MG.gather_to_root(host, dist, rank, world, hg)
-                if rank == 0:
-                    gathered.copy_(hg)
+                src = tile_sets[buf].cpu()
+                dst = torch.zeros((world,) + tuple(src.shape), dtype=torch.uint8) if rank == 0 else None
             else:
-                MG.gather_to_root(tiles, dist, rank, world, gathered)
-            if rank == 0:                               # all B frames of the step in one launch
-                ds.deinterleave_frames(gathered.data_ptr(), frames.data_ptr(), W, H, ROW_BLOCK, world, 3, B,
-                                       rank_stride_bytes=B * tile_bytes, tile_stride_bytes=tile_bytes)
+                src, dst = tile_sets[buf], (gathered_sets[buf] if rank == 0 else None)
+            work = MG.gather_to_root(src, dist, rank, world, dst, async_op=True)
+            this = (work, buf, dst if rehearsal else None)
+            if nbuf == 1:
+                finish(this)
+            else:                                       # the previous step's gather had a whole render to complete
+                if state["pending"] is not None:
+                    finish(state["pending"])
+                state["pending"] = this
 
     def barrier():
+        if state["pending"] is not None:
+            finish(state["pending"])
+            state["pending"] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -416,7 +444,8 @@ def main():
                     "synthetic: P3D_Scenes/mount_low.p3f (12 primitives, 1 light) resolution/accel overridden to the config",
             "config": {"workload": ("SURVEY 8d scaling scene, %d primitives, 1920x1080 depth 4 BVH" % args.prims) if synthetic
                        else "mount_low.p3f 1920x1080 depth 4 BVH (BASELINE config 2)",
-                       "frames_per_step": B, "frames_in_flight": F, "hip_graph": graph is not None,
+                       "frames_per_step": B, "frames_in_flight": F, "hip_graph": graphs is not None,
+                       "gather": ("pipelined" if nbuf == 2 else "after each step") if world > 1 else None,
                        "rays_per_frame": int(rays_frame),
                        "row_block": ROW_BLOCK,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved 16-row blocks + RCCL gather to rank 0" % world,

@@ -49,6 +49,15 @@ def _worker(rank, world, port, scene_file, out_file):
     if rank == 0:
         frame = MG.stitch_reference([g[r].numpy() for r in range(world)], H, RB)
         np.save(out_file, frame)
+    # the pipelined form bench.py uses: two collectives in flight, waited for one step late
+    t2 = torch.flip(t, dims=[1]).contiguous()
+    g1 = torch.zeros_like(gathered) if rank == 0 else None
+    g2 = torch.zeros_like(gathered) if rank == 0 else None
+    w1 = MG.gather_to_root(t, dist, rank, world, g1, async_op=True)
+    w2 = MG.gather_to_root(t2, dist, rank, world, g2, async_op=True)
+    w1.wait(); w2.wait()
+    if rank == 0:
+        assert torch.equal(g1, gathered) and torch.equal(g2, torch.flip(gathered, dims=[2]))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -31,14 +31,14 @@ def stitch_reference(parts, res_y, row_block):
     return out
 
 
-def gather_to_root(tile, dist, rank, world, gathered=None):
+def gather_to_root(tile, dist, rank, world, gathered=None, async_op=False):
     """One collective per step: every rank's compact tile buffer -> rank 0 (direct peer->root
     transfers over xGMI, 7 links in parallel).  `tile` and `gathered` are torch
-    tensors; gathered is [world, *tile.shape] on rank 0."""
+    tensors; gathered is [world, *tile.shape] on rank 0.  async_op=True returns the collective's
+    work handle instead of waiting for it (wait() before touching `gathered` or reusing `tile`)."""
     if world == 1:
-        return tile.unsqueeze(0)
-    if rank == 0:
-        dist.gather(tile, gather_list=list(gathered.unbind(0)), dst=0)
-        return gathered
-    dist.gather(tile, gather_list=None, dst=0)
-    return None
+        return None if async_op else tile.unsqueeze(0)
+    work = dist.gather(tile, gather_list=list(gathered.unbind(0)) if rank == 0 else None, dst=0, async_op=async_op)
+    if async_op:
+        return work
+    return gathered if rank == 0 else None
