@@ -8,7 +8,9 @@
 A step = `--frames-per-step` frames of the configuration's camera, each rendered by the HIP
 kernel into HBM-resident buffers.  With N > 1 every frame is split into interleaved 16-row
 blocks across the ranks (total work fixed: strong scaling) and each step ends with ONE RCCL
-gather of the compact tile buffers to rank 0 plus the de-interleave kernel there.
+gather of the compact tile buffers to rank 0 plus the de-interleave kernel there.  The gather of
+step i is waited for while step i+1 renders into a second set of tile buffers (--gather sync waits
+at once); every step's frames are on rank 0 when the timed region closes.
 value = rays of all frames / max-over-ranks wall time; a ray is one closest-hit or one shadow
 query, counted by the counting build of the same kernel on the same frame.
 
