@@ -116,6 +116,9 @@ struct p3d_scene {
     // of one pass fill with another pass's work, like independent frames do.  Lane 0 is the scene's stream.
     struct Workspace {
         RawBuf rays[kMaxDepth + 2], nodes[kMaxDepth + 2], counts;
+        // counts holds TWO sets of counters: a pass uses set `parity` and its level-1 launch clears the
+        // other one for the pass after it, so only the first pass over a workspace needs a memset
+        int parity = 0; bool clean[2] = {false, false};
         RawBuf rng[kMaxDepth + 2];           // random-stream keys of the queued rays (stochastic features)
         void release() {
             for (auto& b : rays) b.release();
@@ -361,9 +364,12 @@ constexpr int kShards = 64;   // queue shards (power of two); spreads the slot-a
 int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t stream, LaunchParams P, bool count, bool lds,
                        bool packet, size_t shard_px, bool profile) {
     const int D = P.max_depth;
-    uint32_t* counts = (uint32_t*)ws.counts.p;         // [level][shard] ray counts, then node counts
     const size_t n_counts = (size_t)2 * (kMaxDepth + 2) * kShards;
-    HIP_TRY(hipMemsetAsync(counts, 0, n_counts * sizeof(uint32_t), stream));
+    const int par = ws.parity;
+    uint32_t* counts = (uint32_t*)ws.counts.p + (size_t)par * n_counts;    // [level][shard] ray counts, then node counts
+    if (!ws.clean[par]) HIP_TRY(hipMemsetAsync(counts, 0, n_counts * sizeof(uint32_t), stream));
+    P.wf_clear = (uint32_t*)ws.counts.p + (size_t)(1 - par) * n_counts; P.wf_clear_words = (uint32_t)n_counts;
+    ws.clean[par] = false;
     auto rays = [&](int l) { return (l >= 2 && l <= D) ? (RayRec*)ws.rays[l].p : nullptr; };
     auto nodes = [&](int l) { return (l >= 1 && l <= D - 1) ? (NodeRec*)ws.nodes[l].p : nullptr; };
     auto qcount = [&](int l) { return counts + (size_t)l * kShards; };
@@ -379,6 +385,7 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
     P.wf_nodes_self = nodes(1); P.wf_ncount_self = ncount(1); P.wf_ncap_self = cap(1);
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], stream));
     HIP_TRY(launch_wf_primary(P, count, lds, packet, s->occupancy, stream));
+    ws.clean[1 - par] = true; ws.parity = 1 - par;         // the launch that clears the other set is enqueued
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], stream));
     for (int l = 2; l <= D; l++) {
         P.wf_level = l;
@@ -576,7 +583,8 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
             p3d_scene::Workspace& w = s->ws[ln];
             for (int l = 2; l <= D; l++) HIP_TRY(w.rays[l].ensure((shard_px << (l - 1)) * kShards * sizeof(RayRec)));
             for (int l = 1; l <= D - 1; l++) HIP_TRY(w.nodes[l].ensure((shard_px << (l - 1)) * kShards * sizeof(NodeRec)));
-            HIP_TRY(w.counts.ensure((size_t)2 * (kMaxDepth + 2) * kShards * sizeof(uint32_t)));
+            if (!w.counts.p) { w.clean[0] = w.clean[1] = false; }
+            HIP_TRY(w.counts.ensure((size_t)2 * 2 * (kMaxDepth + 2) * kShards * sizeof(uint32_t)));
             if (stochastic)
                 for (int l = 2; l <= D; l++) HIP_TRY(w.rng[l].ensure((shard_px << (l - 1)) * kShards * sizeof(uint32_t)));
         }

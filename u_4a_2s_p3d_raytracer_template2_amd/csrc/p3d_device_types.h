@@ -96,6 +96,7 @@ struct LaunchParams {
     uint32_t wf_cap_in, wf_cap_out, wf_ncap_parent, wf_ncap_self;    // entries per shard
     const RayRec* wf_rays_in;  const uint32_t* wf_count_in;      // level wf_level queue
     RayRec* wf_rays_out;       uint32_t* wf_count_out;           // level wf_level + 1 queue
+    uint32_t* wf_clear; uint32_t wf_clear_words;                  // counters of the next pass, zeroed by the level-1 launch
     NodeRec* wf_nodes_parent;                                     // level wf_level - 1 nodes
     NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
     float* wf_planes; uint64_t wf_plane_stride;                   // [sample][local px][3] clamped sample colours; floats per plane

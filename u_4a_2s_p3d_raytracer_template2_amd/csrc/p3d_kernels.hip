@@ -239,6 +239,10 @@ __device__ __forceinline__ void stamp(const LaunchParams& P, int tile, int k) {
 
 template <bool COUNT, bool LDS, bool PACKET, int OCC, bool STOCH = false>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel(const LaunchParams P) {
+    // the queue counters of the NEXT pass over this workspace (the other half of a double buffer nothing
+    // touches during this pass): cleared here instead of by a memset launch in front of every frame
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < P.wf_clear_words; i += blockDim.x) P.wf_clear[i] = 0u;
     const typename View<LDS>::type sv = View<LDS>::make(P);
     int x, y, row, tile;
     const bool valid = tile_pixel(P, x, y, row, &tile);
