@@ -59,6 +59,7 @@ def lib():
         L.p3o_render.restype = C.c_int
         L.p3o_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(Counters)]
+        L.p3o_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, fp, fp, fp]
         L.p3o_intersect.restype = C.c_int
         L.p3o_intersect.argtypes = [C.c_int, fp, fp, fp, fp, fp]
         L.p3o_aabb_intercepts.restype = C.c_int
@@ -189,6 +190,13 @@ class Scene:
         if rc != 0:
             raise RuntimeError("p3o_render failed: %d" % rc)
         return {"rgb8": rgb8, "rgb32f": f32, "hit_id": hid, "counters": ctr.as_dict()}
+
+    def trace(self, accel, o, d, max_depth=4, soft_shadow=False):
+        """One rayTracing(ray, 1, 1.0) call: unclamped colour."""
+        o, d = f3(o), f3(d)
+        c = np.zeros(3, np.float32)
+        lib().p3o_trace(self.h, int(accel), int(max_depth), int(soft_shadow), _f(o), _f(d), _f(c))
+        return c
 
     # reference-BVH / grid restatement probes
     def refbvh_dump(self):

@@ -1023,7 +1023,7 @@ int p3o_render(p3o_scene* sc, const p3o_params* prm, uint8_t* rgb8, float* rgb32
     p3o_counters total; memset(&total, 0, sizeof total);
     if (threads == 1) {
         memset(&g_ctr, 0, sizeof g_ctr);
-        if (spp != 0) srand(prm->seed);                                   // RT/main.cpp:747
+        srand(prm->seed);                                                 // RT/main.cpp:747 (every frame)
         Tracer T; T.sc = sc; T.prims = &sc->prims; T.bvh = &sc->bvh; T.grid = &sc->grid;
         T.accel = accel; T.max_depth = prm->max_depth; T.break_fixed = prm->break_fixed != 0;
         T.soft_shadow = prm->soft_shadow != 0; T.fuzzy_reflection = prm->fuzzy_reflection != 0; T.spp = (int)spp;
@@ -1059,6 +1059,20 @@ int p3o_render(p3o_scene* sc, const p3o_params* prm, uint8_t* rgb8, float* rgb32
     }
     if (ctr) *ctr = total;
     return 0;
+}
+
+// one rayTracing(ray, 1, 1.0) call (RT/main.cpp:530) on an arbitrary ray, for the shading KATs
+void p3o_trace(p3o_scene* sc, int accel, int max_depth, int soft_shadow, const float* o, const float* d,
+               float* rgb3) {
+    ensure_accel(sc, accel);
+    memset(&g_ctr, 0, sizeof g_ctr);
+    Tracer T; T.sc = sc; T.prims = &sc->prims; T.bvh = &sc->bvh; T.grid = &sc->grid;
+    T.accel = accel; T.max_depth = max_depth; T.break_fixed = false;
+    T.soft_shadow = soft_shadow != 0; T.fuzzy_reflection = false; T.spp = 0;
+    T.last_primary_hit = -1;
+    RayO r; r.o = V3(o[0], o[1], o[2]); r.d = V3(d[0], d[1], d[2]);
+    Col c = T.rayTracing(r, 1, 1.0, true);
+    rgb3[0] = c.r; rgb3[1] = c.g; rgb3[2] = c.b;
 }
 
 // ---- KATs

@@ -6,16 +6,16 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  * The product (u_4a_2s_p3d_raytracer_template2_amd/) never includes, links or calls it.
  *
- * Pinning status (see oracle/README.md and DESIGN.md):
- *   - Vector / AABB / BVH build+traverse / Grid build+traverse / Camera / Color /
- *     u8fromfloat / rand_float are checked against the reference's OWN objects built in
- *     oracle/_ref (tests/test_oracle_vs_ref.py, runs only where /root/reference exists);
- *   - intersectors, shading recursion, render loop and the .p3f loader live in
- *     RT/scene.cpp and RT/main.cpp, which are unbuildable here without stand-ins
- *     (conio.h, GL, DevIL, strcpy_s, MSVC rvalue binding); they are pinned only by the
- *     reference-run counters recorded in SURVEY.md (exact ray counts, intersector call
- *     counts, mode-to-mode pixel-difference counts) and by RT/RT_Output.png (background
- *     quantisation). No reference-written image bytes exist: RGB "parity unpinned" beyond that.
+ * Pinning status: PINNED against the reference's own object code.  oracle/Makefile compiles
+ * RT/vector.cpp, boundingBox.cpp, bvh.cpp, grid.cpp, RT/scene.cpp:1-331 and RT/main.cpp:471-730
+ * (with its globals) unchanged from /root/reference into oracle/_ref/libp3d_ref[_dN].so, and
+ * tests/test_oracle_vs_ref.py checks this restatement against it BIT FOR BIT: vector / AABB /
+ * camera / quantiser / rand helpers, BVH and grid build + both traversals, the four intersectors
+ * (16 000 known answers), single rayTracing() calls, whole frames (float bits, rgb8, Ray::nextId)
+ * for every golden case, 24 generated scenes (all accel modes, depths 1-6), the spp > 0 sample
+ * loop and the SOFT_SHADOW / FUZZY_REFLECTION branches.  tests/golden/*.npz are reference outputs
+ * (tests/golden/make_golden.py).  Not built from the reference, hence pinned only by the scene
+ * files themselves: the .p3f loader (RT/scene.cpp:476-675 calls the DevIL skybox loader).
  */
 #ifndef P3D_ORACLE_H
 #define P3D_ORACLE_H
@@ -72,6 +72,10 @@ void       p3o_scene_camera(const p3o_scene*, float* out19);
  * (first sample when spp>0). Returns 0 on success. */
 int p3o_render(p3o_scene*, const p3o_params*, uint8_t* rgb8, float* rgb32f,
                int32_t* hit_id, p3o_counters* ctr);
+
+/* one rayTracing(ray, 1, 1.0) call on an arbitrary ray (unclamped colour) */
+void p3o_trace(p3o_scene*, int accel, int max_depth, int soft_shadow, const float* o3, const float* d3,
+               float* rgb3);
 
 /* ---- known-answer entry points (unit level) ---- */
 /* prim12: sphere c3,r | triangle p0,p1,p2 | box min3,max3 | plane p0,p1,p2 */

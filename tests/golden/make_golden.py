@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Generate the committed golden fixtures from the CPU oracle (oracle/libp3d_oracle.so).
+"""Generate the committed golden fixtures from the REFERENCE'S OWN object code (oracle/_ref).
 
-Run in the build container:  python tests/golden/make_golden.py
-The reference itself cannot write images here (RT/main.cpp and RT/scene.cpp are unbuildable
-without stand-ins), so these are ORACLE outputs; the oracle is pinned by
-tests/test_oracle_pinned.py (reference-run counters) and tests/test_oracle_vs_ref.py
-(the reference's own compiled objects).
+Run in the build container (needs /root/reference):  python tests/golden/make_golden.py
+Every frame is rendered by the reference's rayTracing() over the reference's Sphere/Triangle/aaBox/
+Plane objects (RT/main.cpp:471-730 and RT/scene.cpp:1-331 compiled unchanged, see oracle/Makefile and
+oracle/ref_harness.cpp); every known answer comes from the reference's intercepts()/getNormal().
+The script also asserts that the oracle restatement reproduces each of them bit for bit, and takes
+the per-kind test counters (which the reference does not keep) from the oracle.
 
 frames.npz   one entry per case "<name>": rgb8 [H,W,3] u8 (bottom row first), rgb32f [H,W,3] f32,
              hit_id [H,W] i32, plus counters; case parameters are in cases.json.
@@ -24,6 +25,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 from conftest import scene_path  # noqa: E402
 from oracle import oracle_py as O  # noqa: E402
+from oracle import ref_py as R  # noqa: E402
 
 # name, scene, (W,H), accel, spp, max_depth, seed
 CASES = [
@@ -87,9 +89,13 @@ def kat(rng, n_each=4000):
     t = np.zeros(len(types), np.float32)
     nrm = np.zeros((len(types), 3), np.float32)
     for i in range(len(types)):
-        h, tt, n = O.intersect(types[i], prims[i], orgs[i], dirs[i])
+        h, tt, n = R.intersect(types[i], prims[i], orgs[i], dirs[i])          # the reference's objects
+        ho, to, no = O.intersect(types[i], prims[i], orgs[i], dirs[i])
+        assert h == ho
         hit[i] = h
         if h:
+            assert np.float32(tt).view(np.uint32) == np.float32(to).view(np.uint32)
+            assert np.array_equal(n.view(np.uint32), no.view(np.uint32))
             t[i] = tt
             nrm[i] = n
     return dict(type=types, prim12=prims, origin=orgs, dir=dirs, hit=hit, t=t, normal=nrm)
@@ -102,10 +108,16 @@ def main():
     for (name, scene, (w, h), accel, spp, depth, seed) in CASES:
         sc = O.Scene(scene_path(scene))
         sc.set_resolution(w, h)
+        rs = R.RefScene.from_oracle_scene(sc, scene_path(scene), res=(w, h), depth=depth)
+        ref = rs.render(accel, spp, seed)                                      # the reference's rayTracing()
         r = sc.render(max_depth=depth, accel=accel, spp=spp, seed=seed, threads=1)
-        frames[name + "/rgb8"] = r["rgb8"]
-        frames[name + "/rgb32f"] = r["rgb32f"]
-        frames[name + "/hit_id"] = r["hit_id"]
+        for k in ("rgb8", "hit_id"):
+            assert np.array_equal(ref[k], r[k]), (name, k)
+        assert np.array_equal(ref["rgb32f"].view(np.uint32), r["rgb32f"].view(np.uint32)), name
+        assert ref["rays"] == r["counters"]["rays"], name
+        frames[name + "/rgb8"] = ref["rgb8"]
+        frames[name + "/rgb32f"] = ref["rgb32f"]
+        frames[name + "/hit_id"] = ref["hit_id"]
         meta[name] = dict(scene=scene, res=[w, h], accel=accel, spp=spp, max_depth=depth, seed=seed,
                           counters=r["counters"])
         print(name, r["counters"]["rays"], "rays")

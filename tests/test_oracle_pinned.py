@@ -1,5 +1,6 @@
-"""The oracle must reproduce every number the reference itself produced when it was run for
-SURVEY.md (tests/golden/reference_counters.json) and the committed golden frames."""
+"""The oracle must reproduce the committed golden frames -- which are REFERENCE output, rendered by
+the reference's own object code (tests/golden/make_golden.py, oracle/_ref) -- and, as a cross-check,
+every number the reference produced when it was run for SURVEY.md (reference_counters.json)."""
 import json
 import os
 
@@ -56,19 +57,27 @@ def test_reference_output_png_background():
     assert [O.u8fromfloat(v) for v in sc.bg()] == [19, 92, 192]
 
 
-def test_golden_frames_are_current():
-    """The committed fixtures are what the oracle produces today (guards silent oracle drift)."""
-    cases = json.load(open(os.path.join(GOLDEN, "cases.json")))
+GOLDEN_CASES = json.load(open(os.path.join(GOLDEN, "cases.json")))
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_CASES))
+def test_oracle_reproduces_the_reference_frames(name):
+    """tests/golden/frames.npz holds REFERENCE output (the reference's own rayTracing() object code,
+    tests/golden/make_golden.py); the oracle must reproduce every frame in float bits, rgb8, primary
+    hit ids and ray count.  Runs wherever the repo is (no /root/reference needed)."""
+    m = GOLDEN_CASES[name]
     frames = np.load(os.path.join(GOLDEN, "frames.npz"))
-    for name in ("c2_mount_low_256x144_d4_bvh", "c4_mount_low_96_d6_spp2", "balls_box_128_d4_none",
-                 "balls_medium_128_d4_bvh", "mount_low_37x23_d4_bvh"):
-        m = cases[name]
-        sc = O.Scene(scene_path(m["scene"]))
-        sc.set_resolution(*m["res"])
-        r = sc.render(max_depth=m["max_depth"], accel=m["accel"], spp=m["spp"], seed=m["seed"])
-        assert np.array_equal(r["rgb8"], frames[name + "/rgb8"]), name
-        assert np.array_equal(r["hit_id"], frames[name + "/hit_id"]), name
-        assert np.array_equal(r["rgb32f"].view(np.uint32), frames[name + "/rgb32f"].view(np.uint32)), name
+    sc = O.Scene(scene_path(m["scene"]))
+    sc.set_resolution(*m["res"])
+    H = m["res"][1]
+    # the un-culled dragon is 1e5 intersector calls per ray (SURVEY Q1): 16 rows of it here
+    y0, y1 = (H // 2 - 8, H // 2 + 8) if m["scene"] == "dragon" else (0, 0)
+    rows = slice(y0, y1) if y1 else slice(None)
+    r = sc.render(max_depth=m["max_depth"], accel=m["accel"], spp=m["spp"], seed=m["seed"], y0=y0, y1=y1)
+    assert np.array_equal(r["rgb8"][rows], frames[name + "/rgb8"][rows]), name
+    assert np.array_equal(r["hit_id"][rows], frames[name + "/hit_id"][rows]), name
+    assert np.array_equal(r["rgb32f"][rows].view(np.uint32), frames[name + "/rgb32f"][rows].view(np.uint32)), name
+    if not y1:
         assert r["counters"] == m["counters"], name
 
 
