@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define P3D_ABI_VERSION 2
+#define P3D_ABI_VERSION 3
 
 typedef enum p3d_status {
     P3D_OK = 0,
@@ -34,7 +34,8 @@ typedef enum p3d_status {
     P3D_ERR_HIP = -2,        /* a HIP runtime call failed                               */
     P3D_ERR_NO_DEVICE = -3,  /* no usable gfx950 device                                 */
     P3D_ERR_LIMIT = -4,      /* scene exceeds a kernel limit (LDS stack, depth)         */
-    P3D_ERR_STATE = -5       /* call made in the wrong state                            */
+    P3D_ERR_STATE = -5,      /* call made in the wrong state                            */
+    P3D_ERR_COMM = -6        /* an RCCL call failed                                     */
 } p3d_status;
 
 /* primitive kinds, RT/scene.h:67-145 */
@@ -242,6 +243,41 @@ int p3d_deinterleave(p3d_scene* scene, const void* gathered, void* frame, int32_
 int p3d_deinterleave_frames(p3d_scene* scene, const void* gathered, void* frames, int32_t res_x, int32_t res_y,
                             int32_t row_block, int32_t world, int32_t bytes_per_pixel, uint64_t rank_stride_bytes,
                             int32_t n_frames, uint64_t tile_stride_bytes, uint64_t frame_stride_bytes);
+
+/* ---- the multi-GPU frame (replaces nothing in the reference, which is one CPU thread:
+ * it is what main()'s "renderScene(); save image" (RT/main.cpp:966-970) becomes on N GPUs) ----
+ * Every rank renders its row blocks (p3d_render with rank / world) into a compact tile buffer of
+ * p3d_local_rows() rows; ONE gather per frame moves the tile buffers to rank 0 over RCCL (grouped
+ * ncclSend / ncclRecv: each peer writes straight into rank 0's memory over its own xGMI link, no ring),
+ * where p3d_deinterleave() restores row order.  Scene + BVH are replicated: one p3d_scene per device. */
+typedef struct p3d_comm p3d_comm;
+#define P3D_COMM_ID_BYTES 128
+
+/* One process per GPU: rank 0 makes an id (ncclGetUniqueId), the launcher carries its 128 bytes to the
+ * other ranks (a torch.distributed / MPI broadcast, a file, ...), then every rank calls p3d_comm_create
+ * with the same id (ncclCommInitRank; blocks until all `world` ranks have called). */
+int p3d_comm_unique_id(void* id_out /* P3D_COMM_ID_BYTES */);
+int p3d_comm_create(const void* id, int rank, int world, int device, p3d_comm** out);
+/* One process driving n GPUs: out[r] is rank r on devices[r] (NULL = devices 0..n-1); ncclCommInitAll. */
+int p3d_comm_create_all(const int* devices, int n, p3d_comm** out /* [n] */);
+int p3d_comm_destroy(p3d_comm* comm);
+int p3d_comm_info(const p3d_comm* comm, int* rank, int* world, int* device);
+
+/* The gather, enqueued on `scene`'s stream (scene and comm on the same device): rank r > 0 sends
+ * tile_bytes from `tile`; rank 0 receives rank r's bytes at gathered + r * tile_bytes and copies its own
+ * tile to gathered + 0 (skipped when tile == gathered).  `gathered` is only read on rank 0.  Device
+ * pointers.  Asynchronous: p3d_sync() / stream order as usual.  world == 1 degenerates to the copy. */
+int p3d_gather(p3d_comm* comm, p3d_scene* scene, const void* tile, void* gathered, uint64_t tile_bytes);
+/* The same for all n ranks of a p3d_comm_create_all() group from ONE thread (their sends and receives
+ * must share one RCCL group): comms[r], scenes[r], tiles[r] belong to rank r. */
+int p3d_gather_all(p3d_comm* const* comms, p3d_scene* const* scenes, const void* const* tiles, int n,
+                   void* gathered, uint64_t tile_bytes);
+
+/* Device memory on a scene's device for callers that have no HIP runtime of their own (the C++ host
+ * layer): allocate / free, and copy to the host (enqueued on the scene's stream, waits for it). */
+int p3d_device_alloc(p3d_scene* scene, uint64_t bytes, void** out);
+int p3d_device_free(p3d_scene* scene, void* ptr);
+int p3d_download(p3d_scene* scene, void* host_dst, const void* device_src, uint64_t bytes);
 
 /* Diagnostic: with a device buffer of (tiles x waves-per-workgroup x 8) uint64 set here, the
  * level-1 kernel writes per-wave 100 MHz timestamps (tile start, after ray generation, after the

@@ -56,6 +56,11 @@ int p3d_pt_sync(p3d_pt* pt);
 /* HIP-event bracket on the handle's stream, like p3d_timer_begin/end */
 int p3d_pt_timer_begin(p3d_pt* pt);
 int p3d_pt_timer_end(p3d_pt* pt, float* elapsed_ms);
+/* Multi-GPU form: the samples of one image are split over the ranks (first_frame =
+ * rank, frame_stride = world) and the `linear` sums are added up on rank 0: ncclReduce(sum) over `comm`
+ * (see p3d_hip.h), in place on a device buffer of `count` floats, enqueued on the handle's stream. */
+struct p3d_comm;
+int p3d_pt_reduce_sum(struct p3d_comm* comm, p3d_pt* pt, float* linear, uint64_t count);
 /* integer hash of PT/common.glsl:31-36 evaluated on the device (known-answer probe) */
 int p3d_pt_debug_hash(int device, uint32_t n, const uint32_t* a, const uint32_t* b, uint32_t* out);
 

@@ -211,6 +211,32 @@ def test_render_is_idempotent_and_device_outputs_match_host_outputs():
     ds.close()
 
 
+def test_sample_frames_never_write_past_the_image_in_device_buffers():
+    """spp > 0 into caller-owned DEVICE planes of exactly res_y rows (world == 1, include/p3d_hip.h) at a
+    height that is not a multiple of the 16-row block: the rows the compact buffer is padded with must not
+    be written (canary rows behind the image stay intact), and the image equals the host-buffer render."""
+    torch = pytest.importorskip("torch")
+    hs = P.HostScene(scene_path("mount_low"))
+    W, H, pad = 96, 70, 12
+    hs.set_resolution(W, H)
+    ds = P.DeviceScene.from_host(hs)
+    cam = hs.camera()
+    smp = hs.samples(99, 2)
+    ref = ds.render(cam, max_depth=4, accel=2, spp=2, samples=smp)
+    dev8 = torch.full((H + pad, W, 3), 0xA5, dtype=torch.uint8, device="cuda")
+    devf = torch.full((H + pad, W, 3), -7.0, dtype=torch.float32, device="cuda")
+    devh = torch.full((H + pad, W), -99, dtype=torch.int32, device="cuda")
+    for kw in (dict(wavefront=True), dict(tree=True)):
+        ds.render_device(cam, rgb8_ptr=dev8.data_ptr(), rgb32f_ptr=devf.data_ptr(), hit_ptr=devh.data_ptr(),
+                         max_depth=4, accel=2, spp=2, samples=smp, **kw)
+        ds.sync()
+        assert (dev8[H:] == 0xA5).all() and (devf[H:] == -7.0).all() and (devh[H:] == -99).all(), kw
+        assert np.array_equal(dev8[:H].cpu().numpy(), ref["rgb8"])
+        assert np.array_equal(devf[:H].cpu().numpy().view(np.uint32), ref["rgb32f"].view(np.uint32))
+        assert np.array_equal(devh[:H].cpu().numpy(), ref["hit_id"])
+    ds.close()
+
+
 def test_error_behaviour():
     hs = P.HostScene(scene_path("mount_low"))
     ds = P.DeviceScene.from_host(hs)

@@ -22,12 +22,42 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libp3d_hip.so does not export %s" % name
     assert sorted(api.C_ABI_SYMBOLS) == declared
-    assert L.p3d_abi_version() == 2
+    assert L.p3d_abi_version() == 3
     pt_header = open(os.path.join(REPO, "include", "p3d_pathtracer.h")).read()
     pt_declared = sorted(set(re.findall(r"\b(p3d_pt_[a-z_]+)\s*\(", pt_header)))
     assert pt_declared == sorted(api.PT_C_ABI_SYMBOLS)
     for name in pt_declared:
         assert hasattr(L, name), "libp3d_hip.so does not export %s" % name
+
+
+def test_library_links_rccl_and_the_gather_rejects_bad_arguments():
+    """the frame gather lives behind the C-ABI (csrc/p3d_comm.cpp) and is RCCL's
+    ncclSend/ncclRecv, not a Python-side collective.  No GPU here: only linkage and argument checks."""
+    import subprocess
+    dyn = subprocess.check_output(["readelf", "-d", api.LIB_PATH]).decode()
+    assert "librccl.so" in dyn, "libp3d_hip.so is not linked against RCCL"
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", api.LIB_PATH]).decode()
+    for sym in ("ncclCommInitAll", "ncclCommInitRank", "ncclGetUniqueId", "ncclSend", "ncclRecv",
+                "ncclGroupStart", "ncclGroupEnd", "ncclReduce"):
+        assert sym in und, sym
+    L = P.lib()
+    h = C.c_void_p()
+    ident = (C.c_ubyte * api.COMM_ID_BYTES)()
+    for (rank, world) in ((2, 2), (-1, 4), (0, 0), (0, 65)):
+        assert L.p3d_comm_create(ident, rank, world, 0, C.byref(h)) == -1          # P3D_ERR_ARG
+        assert h.value is None and L.p3d_last_error()
+    assert L.p3d_comm_create(None, 0, 1, 0, C.byref(h)) == -1
+    hs = (C.c_void_p * 4)()
+    assert L.p3d_comm_create_all(None, 0, hs) == -1
+    assert L.p3d_comm_create_all(None, 100, hs) == -1
+    assert L.p3d_gather(None, None, None, None, 16) == -1
+    assert L.p3d_gather_all(None, None, None, 2, None, 16) == -1
+    assert L.p3d_comm_destroy(None) == 0
+    with pytest.raises(P.P3DError):                 # no GPU in the build container: an error, never a fallback
+        if P.device_count() == 0:
+            P.Comm.create_all([0])
+        else:
+            raise P.P3DError("GPU present: the hardware path is covered by tests/test_gpu_multigpu.py")
 
 
 def test_missing_extension_fails_loudly(monkeypatch):

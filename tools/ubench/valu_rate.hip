@@ -1,0 +1,92 @@
+// valu_rate.hip -- micro-benchmark (tool, not product): issue rate of scalar vs packed FP32 VALU ops and
+// of the IEEE divide / sqrt expansions on gfx950, at 1..8 waves per SIMD.  Prints cycles per
+// wave-instruction per SIMD.  Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_rate.hip -o tools/ubench/valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP 64
+#define ITERS 256
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void k(float* out, unsigned long long* cyc, float seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float m = 1.0001f;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; r++) {
+            if (KIND == 0) {          // 8 independent v_mul_f32
+                asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                             "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+            } else if (KIND == 1) {   // 4 independent v_pk_mul_f32 (same flops as 8 v_mul)
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, mm = {m, m};
+                asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(mm));
+                a0 = p0.x; a1 = p0.y; a2 = p1.x; a3 = p1.y; a4 = p2.x; a5 = p2.y; a6 = p3.x; a7 = p3.y;
+            } else if (KIND == 2) {   // dependent chain of v_mul_f32
+                asm volatile("v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n"
+                             "v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n"
+                             : "+v"(a0) : "v"(m));
+            } else if (KIND == 3) {   // dependent chain of v_pk_mul_f32
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 p0 = {a0, a1}, mm = {m, m};
+                asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n"
+                             "v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1\n"
+                             : "+v"(p0) : "v"(mm));
+                a0 = p0.x; a1 = p0.y;
+            } else if (KIND == 4) {   // 8 IEEE divides (compiler expansion), independent
+                a0 = m / a0; a1 = m / a1; a2 = m / a2; a3 = m / a3; a4 = m / a4; a5 = m / a5; a6 = m / a6; a7 = m / a7;
+            } else if (KIND == 5) {   // 8 IEEE sqrt
+                a0 = __builtin_sqrtf(a0 + 2.f); a1 = __builtin_sqrtf(a1 + 2.f); a2 = __builtin_sqrtf(a2 + 2.f); a3 = __builtin_sqrtf(a3 + 2.f);
+                a4 = __builtin_sqrtf(a4 + 2.f); a5 = __builtin_sqrtf(a5 + 2.f); a6 = __builtin_sqrtf(a6 + 2.f); a7 = __builtin_sqrtf(a7 + 2.f);
+            } else if (KIND == 6) {   // 8 v_mov_b32
+                asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n"
+                             "v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (KIND == 7) {   // 8 v_cndmask
+                asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                             "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int KIND>
+static void run(const char* name, int insts_per_rep8) {
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, 256 * 1024 * 4 * 8); hipMalloc(&cyc, 256 * 16 * 8 * 8);
+    for (int waves_per_simd : {1, 2, 4}) {
+        int threads = 64 * 4 * waves_per_simd;    // one block per CU
+        hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, 1.0f);
+        hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, 1.0f);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h(256 * threads / 64);
+        hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+        double s = 0; for (auto v : h) s += (double)v;
+        double per_wave = s / h.size();
+        double n_inst = (double)ITERS * (REP / 8) * insts_per_rep8;
+        // s_memtime ticks at 100 MHz?  report both raw ticks per instruction and per-SIMD rate
+        printf("%-28s waves/SIMD %d: %.2f ticks per wave-instr (per wave), %.2f ticks per wave-instr per SIMD\n", name,
+               waves_per_simd, per_wave / n_inst, per_wave / n_inst / waves_per_simd);
+    }
+    hipFree(out); hipFree(cyc);
+}
+
+int main() {
+    run<0>("v_mul_f32 x8 indep", 8);
+    run<1>("v_pk_mul_f32 x4 indep", 4);
+    run<2>("v_mul_f32 dependent", 8);
+    run<3>("v_pk_mul_f32 dependent", 8);
+    run<4>("IEEE fdiv x8 (expansion)", 8);
+    run<5>("IEEE sqrt x8 (expansion)", 8);
+    run<6>("v_mov_b32 x8", 8);
+    run<7>("v_cndmask x8", 8);
+    return 0;
+}

@@ -7,7 +7,8 @@ import sys
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libp3d_hip.so")
+# P3D_LIB: an alternative build of the same library (tuning experiments under tools/ only)
+LIB_PATH = os.environ.get("P3D_LIB") or os.path.join(_PKG, "libp3d_hip.so")
 
 ACCEL_NONE, ACCEL_GRID, ACCEL_BVH = 0, 1, 2
 FLAG_COUNTERS = 1
@@ -78,7 +79,9 @@ class SceneStats(C.Structure):
 C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_scene_create",
                  "p3d_scene_destroy", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
                  "p3d_get_counters", "p3d_get_profile", "p3d_last_schedule", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end", "p3d_deinterleave_frames",
-                 "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_set_stamps"]
+                 "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_set_stamps",
+                 "p3d_comm_unique_id", "p3d_comm_create", "p3d_comm_create_all", "p3d_comm_destroy", "p3d_comm_info",
+                 "p3d_gather", "p3d_gather_all", "p3d_device_alloc", "p3d_device_free", "p3d_download"]
 
 
 def build_native(verbose=False):
@@ -128,6 +131,18 @@ def lib():
     L.p3d_deinterleave.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_uint64]
     L.p3d_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    L.p3d_comm_unique_id.argtypes = [C.c_void_p]
+    L.p3d_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.p3d_comm_create_all.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.p3d_comm_destroy.argtypes = [C.c_void_p]
+    L.p3d_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.p3d_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.p3d_gather_all.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int,
+                                 C.c_void_p, C.c_uint64]
+    L.p3d_device_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.p3d_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.p3d_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.p3d_pt_reduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.p3d_debug_intersect.argtypes = [C.c_int, C.c_uint32] + [C.c_void_p] * 7
     # host shim
     L.p3dh_scene_load.restype = C.c_void_p
@@ -169,7 +184,7 @@ class PtOutputs(C.Structure):
 
 # include/p3d_pathtracer.h
 PT_C_ABI_SYMBOLS = ["p3d_pt_create", "p3d_pt_destroy", "p3d_pt_set_stream", "p3d_pt_render", "p3d_pt_sync",
-                    "p3d_pt_timer_begin", "p3d_pt_timer_end", "p3d_pt_debug_hash"]
+                    "p3d_pt_timer_begin", "p3d_pt_timer_end", "p3d_pt_debug_hash", "p3d_pt_reduce_sum"]
 
 
 def _check(rc, what):
@@ -392,6 +407,73 @@ class DeviceScene:
     def deinterleave(self, gathered_ptr, frame_ptr, res_x, res_y, row_block, world, bpp, rank_stride_bytes=0):
         _check(lib().p3d_deinterleave(self.h, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), res_x, res_y,
                                       row_block, world, bpp, int(rank_stride_bytes)), "p3d_deinterleave")
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 bytes rank 0 hands to the other ranks (ncclGetUniqueId behind the C-ABI)."""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    _check(lib().p3d_comm_unique_id(buf), "p3d_comm_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    """p3d_comm: one rank of the RCCL group the frame's gather runs on (include/p3d_hip.h)."""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle)
+
+    @classmethod
+    def create(cls, unique_id, rank, world, device):
+        """One process per GPU: every rank calls this with rank 0's comm_unique_id() bytes."""
+        h = C.c_void_p()
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id) if unique_id is not None else None
+        _check(lib().p3d_comm_create(buf, int(rank), int(world), int(device), C.byref(h)), "p3d_comm_create")
+        return cls(h.value)
+
+    @classmethod
+    def create_all(cls, devices):
+        """One process driving len(devices) GPUs: returns the ranks in order."""
+        n = len(devices)
+        devs = (C.c_int * max(n, 1))(*devices)
+        hs = (C.c_void_p * max(n, 1))()
+        _check(lib().p3d_comm_create_all(devs, n, hs), "p3d_comm_create_all")
+        return [cls(hs[i]) for i in range(n)]
+
+    def info(self):
+        r, w, d = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().p3d_comm_info(self.h, C.byref(r), C.byref(w), C.byref(d)), "p3d_comm_info")
+        return r.value, w.value, d.value
+
+    def gather(self, scene, tile_ptr, gathered_ptr, tile_bytes):
+        """Enqueue this rank's part of the frame gather on `scene`'s stream (device pointers)."""
+        _check(lib().p3d_gather(self.h, scene.h, C.c_void_p(tile_ptr), C.c_void_p(gathered_ptr or None),
+                                int(tile_bytes)), "p3d_gather")
+
+    def pt_reduce_sum(self, pt, linear_ptr, count):
+        _check(lib().p3d_pt_reduce_sum(self.h, pt.h, C.c_void_p(linear_ptr), int(count)), "p3d_pt_reduce_sum")
+
+    def close(self):
+        if self.h:
+            lib().p3d_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gather_all(comms, scenes, tile_ptrs, gathered_ptr, tile_bytes):
+    """All ranks of a Comm.create_all() group from one thread (their sends / receives share one RCCL group)."""
+    n = len(comms)
+    cs = (C.c_void_p * n)(*[c.h.value for c in comms])
+    ss = (C.c_void_p * n)(*[s.h.value for s in scenes])
+    ts = (C.c_void_p * n)(*[int(t) for t in tile_ptrs])
+    _check(lib().p3d_gather_all(cs, ss, ts, n, C.c_void_p(gathered_ptr), int(tile_bytes)), "p3d_gather_all")
 
 
 def debug_intersect(ptype, prim12, origin, direction, device=0):

@@ -1,7 +1,8 @@
 // p3d_render -- command-line front end: the offline branch of the reference's main()
 // (RT/main.cpp:949-976: init_scene -> renderScene -> save image) on an MI355X.
 //   p3d_render <scene.p3f> [--res W H] [--accel 0|1|2] [--depth D] [--spp N] [--seed S]
-//              [--device K] [--out image.png|image.ppm] [--counters] [--soft-shadow] [--fuzzy-reflection]
+//              [--device K | --gpus N] [--out image.png|image.ppm] [--counters] [--soft-shadow] [--fuzzy-reflection]
+// --gpus N: devices 0..N-1 each render every N-th block of 16 rows, one RCCL gather to device 0.
 // Defaults are the reference's: resolution / accel / spp from the file, MAX_DEPTH 4.
 #include <chrono>
 #include <cstdio>
@@ -26,7 +27,7 @@ static int save_ppm(const char* path, const std::vector<uint8_t>& img, int w, in
 int main(int argc, char** argv) {
     if (argc < 2) {
         fprintf(stderr, "usage: %s scene.p3f [--res W H] [--accel A] [--depth D] [--spp N] [--seed S] "
-                        "[--device K] [--out file.ppm] [--counters] [--soft-shadow] [--fuzzy-reflection]\n", argv[0]);
+                        "[--device K | --gpus N] [--out file.ppm] [--counters] [--soft-shadow] [--fuzzy-reflection]\n", argv[0]);
         return 2;
     }
     RenderOptions opt;
@@ -41,6 +42,7 @@ int main(int argc, char** argv) {
         else if (a == "--spp") { need(1); opt.spp = atoi(argv[++i]); }
         else if (a == "--seed") { need(1); opt.seed = (unsigned)strtoul(argv[++i], nullptr, 10); }
         else if (a == "--device") { need(1); opt.device = atoi(argv[++i]); }
+        else if (a == "--gpus") { need(1); opt.gpus = atoi(argv[++i]); }
         else if (a == "--out") { need(1); out = argv[++i]; }
         else if (a == "--counters") opt.counters = true;
         else if (a == "--soft-shadow") opt.SOFT_SHADOW = true;

@@ -8,6 +8,8 @@
 #include <fstream>
 #include <sstream>
 
+extern "C" int p3d_internal_set_error(int code, const char* msg);
+
 namespace p3d_host {
 
 static const float kEpsilon = 0.001f;                       // RT/macros.h:1
@@ -359,15 +361,88 @@ int save_png(const char* path, const uint8_t* img, int w, int h) {
 }
 
 // ---------------------------------------------------------------- renderScene drop-in
+namespace {
+
+// the frame on opt.gpus devices of this process: scene + BVH replicated, interleaved row blocks per rank
+// (p3d_render rank / world), ONE gather per plane into device 0 (p3d_gather_all over RCCL), row order
+// restored there (p3d_deinterleave), then the download the single-GPU path also pays
+int render_multi_gpu(const Scene::Flat& flat, const p3d_camera& cam, p3d_render_params prm, const RenderOptions& opt,
+                     bool want_colors, bool want_hit, RenderResult& out) {
+    const int n = opt.gpus, row_block = 16;
+    std::vector<p3d_scene*> dev(n, nullptr);
+    std::vector<p3d_comm*> comm(n, nullptr);
+    struct Plane { int bpp; void* host; std::vector<void*> tile; void* gathered = nullptr; void* frame = nullptr; };
+    std::vector<Plane> planes;
+    int rc = P3D_OK;
+    auto cleanup = [&]() {
+        for (auto& pl : planes) {
+            for (int r = 1; r < n && r < (int)pl.tile.size(); r++) if (dev[r]) p3d_device_free(dev[r], pl.tile[r]);
+            if (dev[0]) { p3d_device_free(dev[0], pl.gathered); p3d_device_free(dev[0], pl.frame); }
+        }
+        for (auto* c : comm) p3d_comm_destroy(c);
+        for (auto* d : dev) p3d_scene_destroy(d);
+    };
+    for (int r = 0; r < n && !rc; r++) rc = p3d_scene_create(&flat.desc, nullptr, r, &dev[r]);
+    if (!rc) rc = p3d_comm_create_all(nullptr, n, comm.data());
+    if (rc) { cleanup(); return rc; }
+    const size_t npx = (size_t)cam.res_x * cam.res_y;
+    const size_t tile_px = (size_t)p3d_local_rows(cam.res_y, row_block, n) * cam.res_x;
+    out.img_Data.assign(npx * 3, 0);
+    planes.push_back(Plane{3, out.img_Data.data(), {}});
+    if (want_colors) { out.colors.assign(npx * 3, 0.0f); planes.push_back(Plane{12, out.colors.data(), {}}); }
+    if (want_hit) { out.hit_id.assign(npx, -1); planes.push_back(Plane{4, out.hit_id.data(), {}}); }
+    for (auto& pl : planes) {
+        pl.tile.assign(n, nullptr);
+        if (!rc) rc = p3d_device_alloc(dev[0], (uint64_t)tile_px * pl.bpp * n, &pl.gathered);
+        if (!rc) rc = p3d_device_alloc(dev[0], (uint64_t)npx * pl.bpp, &pl.frame);
+        pl.tile[0] = pl.gathered;                                   // rank 0 renders straight into its slot
+        for (int r = 1; r < n && !rc; r++) rc = p3d_device_alloc(dev[r], (uint64_t)tile_px * pl.bpp, &pl.tile[r]);
+    }
+    if (!rc) rc = p3d_timer_begin(dev[0]);
+    for (int r = 0; r < n && !rc; r++) {
+        prm.rank = r; prm.world = n; prm.row_block = row_block;
+        p3d_outputs o;
+        o.memory = 1; o.rgb8 = (uint8_t*)planes[0].tile[r]; o.rgb32f = nullptr; o.hit_id = nullptr;
+        for (auto& pl : planes) {
+            if (pl.bpp == 12) o.rgb32f = (float*)pl.tile[r];
+            if (pl.bpp == 4) o.hit_id = (int32_t*)pl.tile[r];
+        }
+        rc = p3d_render(dev[r], &cam, &prm, &o);
+    }
+    for (auto& pl : planes) {
+        std::vector<const void*> tiles(pl.tile.begin(), pl.tile.end());
+        if (!rc) rc = p3d_gather_all(comm.data(), dev.data(), tiles.data(), n, pl.gathered, (uint64_t)tile_px * pl.bpp);
+        if (!rc) rc = p3d_deinterleave(dev[0], pl.gathered, pl.frame, cam.res_x, cam.res_y, row_block, n, pl.bpp, 0);
+    }
+    if (!rc) rc = p3d_timer_end(dev[0], &out.kernel_ms);
+    for (auto& pl : planes)
+        if (!rc) rc = p3d_download(dev[0], pl.host, pl.frame, (uint64_t)npx * pl.bpp);
+    if (!rc && opt.counters) {
+        memset(&out.counters, 0, sizeof out.counters);
+        for (int r = 0; r < n && !rc; r++) {
+            p3d_counters c;
+            rc = p3d_get_counters(dev[r], &c);
+            out.counters.closest_queries += c.closest_queries; out.counters.shadow_queries += c.shadow_queries;
+            out.counters.box_tests += c.box_tests; out.counters.sphere_tests += c.sphere_tests;
+            out.counters.tri_tests += c.tri_tests; out.counters.aabox_tests += c.aabox_tests;
+            out.counters.plane_tests += c.plane_tests; out.counters.pixels += c.pixels;
+        }
+    }
+    std::string keep = rc ? p3d_last_error() : "";
+    cleanup();
+    if (rc) p3d_internal_set_error(rc, keep.c_str());
+    return rc;
+}
+
+}  // namespace
+
 int renderScene(const Scene& scene, const RenderOptions& opt, bool want_colors, bool want_hit, RenderResult& out,
                 std::string* err) {
     auto bad = [&](int rc) { if (err) *err = p3d_last_error(); return rc; };
     if (!scene.GetCamera()) { if (err) *err = "scene has no camera"; return P3D_ERR_ARG; }
+    if (opt.gpus < 1 || opt.gpus > 64) { if (err) *err = "gpus must be in 1..64"; return P3D_ERR_ARG; }
     Scene::Flat flat;
     scene.flatten(flat);
-    p3d_scene* dev = nullptr;
-    int rc = p3d_scene_create(&flat.desc, nullptr, opt.device, &dev);
-    if (rc) return bad(rc);
     p3d_camera cam;
     scene.GetCamera()->describe(&cam);
     p3d_render_params prm;
@@ -385,6 +460,13 @@ int renderScene(const Scene& scene, const RenderOptions& opt, bool want_colors, 
         generate_samples(opt.seed, cam.res_x, cam.res_y, prm.spp, cam.aperture, samples.data());
         prm.samples = samples.data();
     }
+    if (opt.gpus > 1) {
+        int rc = render_multi_gpu(flat, cam, prm, opt, want_colors, want_hit, out);
+        return rc ? bad(rc) : P3D_OK;
+    }
+    p3d_scene* dev = nullptr;
+    int rc = p3d_scene_create(&flat.desc, nullptr, opt.device, &dev);
+    if (rc) return bad(rc);
     size_t npx = (size_t)cam.res_x * cam.res_y;
     out.img_Data.assign(npx * 3, 0);
     if (want_colors) out.colors.assign(npx * 3, 0.0f);

@@ -212,6 +212,7 @@ struct RenderOptions {
     int spp = -1;             // -1 = scene->GetSamplesPerPixel()
     unsigned seed = 12345;    // replaces time(NULL)
     int device = 0;
+    int gpus = 1;             // > 1: devices 0..gpus-1 render interleaved 16-row blocks, one RCCL gather to device 0
     bool counters = false;
     // the reference's distribution-ray-tracing globals (RT/main.cpp:41,43); ANTI_ALIASING and
     // DEPTH_OF_FIELD follow spp > 0 as in RT/main.cpp:943-944

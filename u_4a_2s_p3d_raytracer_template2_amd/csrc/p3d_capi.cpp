@@ -156,6 +156,12 @@ struct p3d_scene {
 };
 
 extern "C" int p3d_internal_set_error(int code, const char* msg) { g_err = msg ? msg : ""; return code; }
+// device and stream a scene is bound to (for p3d_comm.cpp)
+extern "C" int p3d_internal_scene_binding(p3d_scene* s, int* device, void** stream) {
+    if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
+    *device = s->device; *stream = (void*)s->stream;
+    return P3D_OK;
+}
 
 extern "C" {
 
@@ -720,6 +726,26 @@ int p3d_deinterleave_frames(p3d_scene* s, const void* gathered, void* frames, in
 int p3d_deinterleave(p3d_scene* s, const void* gathered, void* frame, int32_t res_x, int32_t res_y,
                      int32_t row_block, int32_t world, int32_t bpp, uint64_t rank_stride_bytes) {
     return p3d_deinterleave_frames(s, gathered, frame, res_x, res_y, row_block, world, bpp, rank_stride_bytes, 1, 0, 0);
+}
+
+int p3d_device_alloc(p3d_scene* s, uint64_t bytes, void** out) {
+    if (!s || !out) return fail(P3D_ERR_ARG, "scene/out is NULL");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMalloc(out, bytes ? (size_t)bytes : 1));
+    return P3D_OK;
+}
+int p3d_device_free(p3d_scene* s, void* ptr) {
+    if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
+    HIP_TRY(hipSetDevice(s->device));
+    if (ptr) HIP_TRY(hipFree(ptr));
+    return P3D_OK;
+}
+int p3d_download(p3d_scene* s, void* host_dst, const void* device_src, uint64_t bytes) {
+    if (!s || !host_dst || !device_src) return fail(P3D_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(host_dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return P3D_OK;
 }
 
 int p3d_debug_intersect(int device, uint32_t n, const uint32_t* type, const float* prim12, const float* origin,

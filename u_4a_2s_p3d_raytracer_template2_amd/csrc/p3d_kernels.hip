@@ -73,6 +73,10 @@ __device__ __forceinline__ void sink_sample(const LaunchParams& P, size_t p, V3 
 __global__ __launch_bounds__(256) void sum_samples_kernel(const LaunchParams P, size_t first_px, size_t n_px) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_px; i += (size_t)gridDim.x * blockDim.x) {
         const size_t p = first_px + i;
+        // rows past the image (the compact buffer is padded to whole row blocks) are never written:
+        // a caller's device plane only holds res_y rows when world == 1 (include/p3d_hip.h)
+        const int row = (int)(p / (size_t)P.res_x), blk = row / P.row_block;
+        if ((blk * P.world + P.rank) * P.row_block + (row - blk * P.row_block) >= P.res_y) continue;
         V3 acc = mk(0.0f, 0.0f, 0.0f);
         for (int smp = 0; smp < P.wf_nsamples; smp++) {
             const float* a = P.wf_planes + (size_t)smp * P.wf_plane_stride + 3 * p;

@@ -73,6 +73,12 @@ int p3d_pt_destroy(p3d_pt* h) {
     delete h;
     return P3D_OK;
 }
+// device and stream a handle is bound to (for p3d_comm.cpp)
+int p3d_internal_pt_binding(p3d_pt* h, int* device, void** stream) {
+    if (!h) return fail(P3D_ERR_ARG, "handle is NULL");
+    *device = h->device; *stream = (void*)h->stream;
+    return P3D_OK;
+}
 int p3d_pt_set_stream(p3d_pt* h, void* s) {
     if (!h) return fail(P3D_ERR_ARG, "handle is NULL");
     h->stream = s ? (hipStream_t)s : h->own_stream;
