@@ -130,9 +130,16 @@ typedef struct p3d_render_params {
 #define P3D_FEATURE_FUZZY_REFLECTION 2u
 
 #define P3D_FLAG_COUNTERS 1u     /* accumulate p3d_counters on the device (slower kernels)  */
-#define P3D_FLAG_WAVEFRONT 32u   /* force the wavefront schedule (the default for scenes up to 2 MiB; for larger
-                                    ones the library times one frame of each schedule per configuration and
-                                    keeps the faster -- results are bit-identical either way)        */
+/* Kernel schedules: three ways to run the same per-node code, bit-identical frames.  Default: the tile
+ * schedule for scenes up to 2 MiB; for larger ones the library times every schedule on the first frames of a
+ * configuration (two frames each, the first one untimed) and keeps the fastest.  At most one of the three
+ * forcing flags may be set. */
+#define P3D_FLAG_TILE_KERNEL 64u /* ONE launch per frame: persistent 256-thread workgroups draw 16x16-pixel tiles and
+                                    run a tile's whole ray tree level by level among themselves (queues in a
+                                    private workspace slot, counters in LDS, no global atomics between levels)  */
+#define P3D_FLAG_WAVEFRONT 32u   /* one launch per tree level over the whole frame + resolve launches          */
+#define P3D_FLAG_DEVICE_SAMPLES 128u /* p3d_render_params::samples is a DEVICE pointer on the scene's device (same
+                                    layout): the caller uploaded the sample array once instead of per call    */
 #define P3D_FLAG_PROFILE 16u     /* bracket the frame and its dominant kernel (the level-1 /
                                     tree launch) with HIP events for p3d_get_profile()           */
 #define P3D_FLAG_NO_PACKET 8u    /* per-lane BVH walk even for trees small enough for the
@@ -217,7 +224,8 @@ int p3d_set_tuning(p3d_scene* scene, int32_t xcd_chunk, int32_t workspace_mib, i
 int p3d_get_profile(p3d_scene* scene, float* frame_ms, float* kernel_ms);
 
 /* Kernel schedule the most recent p3d_render() of this scene used: 0 = wavefront (level kernels),
- * 1 = tree (one launch). P3D_ERR_STATE before the first render. */
+ * 1 = tree (one launch, per-lane stacks), 2 = tile (one launch, per-tile levels). P3D_ERR_STATE before the
+ * first render. */
 int p3d_last_schedule(p3d_scene* scene, int32_t* schedule);
 
 /* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the
@@ -274,9 +282,10 @@ int p3d_gather_all(p3d_comm* const* comms, p3d_scene* const* scenes, const void*
                    void* gathered, uint64_t tile_bytes);
 
 /* Device memory on a scene's device for callers that have no HIP runtime of their own (the C++ host
- * layer): allocate / free, and copy to the host (enqueued on the scene's stream, waits for it). */
+ * layer): allocate / free, and copy from / to the host (enqueued on the scene's stream, waits for it). */
 int p3d_device_alloc(p3d_scene* scene, uint64_t bytes, void** out);
 int p3d_device_free(p3d_scene* scene, void* ptr);
+int p3d_upload(p3d_scene* scene, void* device_dst, const void* host_src, uint64_t bytes);
 int p3d_download(p3d_scene* scene, void* host_dst, const void* device_src, uint64_t bytes);
 
 /* Diagnostic: with a device buffer of (tiles x waves-per-workgroup x 8) uint64 set here, the

@@ -51,6 +51,11 @@ CASES = [
     # ragged sizes: not multiples of the 16x16 tile
     ("mount_low_37x23_d4_bvh", "mount_low", (37, 23), 2, 0, 4, 0),
     ("mount_low_1x1_d1", "mount_low", (1, 1), 2, 0, 1, 0),
+    # GRID mode: per-cell closest hits, planes only inside their default [-1,1]^3 box, shadow rays
+    # that miss the grid count as shadowed (RT/grid.cpp:327-328)
+    ("balls_medium_128_d4_grid", "balls_medium", (128, 128), 1, 0, 4, 0),
+    ("balls_box_128_d3_grid", "balls_box", (128, 128), 1, 0, 3, 0),
+    ("dof_64_d4_spp2_grid", "dof", (64, 64), 1, 2, 4, 4321),
 ]
 
 

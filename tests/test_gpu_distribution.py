@@ -28,10 +28,10 @@ def load(name):
 @pytest.mark.parametrize("name,accel,depth", [("mount_low", 2, 4), ("balls_low", 0, 3), ("balls_low", 1, 2), ("balls_medium", 2, 3)])
 def test_soft_shadow_grid_matches_oracle(name, accel, depth):
     sc, hs, ds = load(name)
-    ref = sc.render(max_depth=depth, accel=2 if accel == 1 else accel, spp=0, soft_shadow=True)
-    plain = sc.render(max_depth=depth, accel=2 if accel == 1 else accel, spp=0)
+    ref = sc.render(max_depth=depth, accel=accel, spp=0, soft_shadow=True)
+    plain = sc.render(max_depth=depth, accel=accel, spp=0)
     assert ref["counters"]["shadow_queries"] > 8 * plain["counters"]["shadow_queries"]      # 16 sub-lights per light
-    for kw in (dict(), dict(tree=True), dict(no_lds=True, no_packet=True)):
+    for kw in (dict(), dict(tree=True), dict(wavefront=True), dict(no_lds=True, no_packet=True)):
         out = ds.render(hs.camera(), max_depth=depth, accel=accel, spp=0, soft_shadow=True, counters=True, **kw)
         assert np.array_equal(out["hit_id"], ref["hit_id"])
         assert np.abs(out["rgb32f"] - ref["rgb32f"]).max() <= 1e-4
@@ -87,6 +87,10 @@ def test_random_streams_are_reproducible_and_shard_independent():
     # LDS-resident and HBM-resident scene paths draw the same numbers
     d = ds.render(cam, no_lds=True, no_packet=True, **kw)
     assert np.array_equal(d["rgb32f"], a["rgb32f"])
+    # ... and so do the tile schedule and the wavefront schedule
+    for sched in ("tile", "wavefront"):
+        e = ds.render(cam, **dict(kw, **{sched: True}))
+        assert ds.last_schedule() == sched and np.array_equal(e["rgb32f"], a["rgb32f"])
     ds.close()
 
 

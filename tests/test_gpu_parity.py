@@ -101,11 +101,11 @@ def test_device_intersectors_match_oracle_live_including_planes():
     assert np.array_equal(t[hit].view(np.uint32), exp_t[hit].view(np.uint32))
 
 
-@pytest.mark.parametrize("schedule", ["wavefront", "tree"])
+@pytest.mark.parametrize("schedule", ["tile", "wavefront", "tree"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_frame_matches_golden_fixture(frames, name, schedule):
     m = CASES[name]
-    out = gpu_render(m, counters=True, tree=(schedule == "tree"), wavefront=(schedule == "wavefront"))
+    out = gpu_render(m, counters=True, **{schedule: True})
     compare(out, frames[name + "/rgb8"], frames[name + "/rgb32f"], frames[name + "/hit_id"], name)
     c = out["counters"]
     assert c["closest_queries"] == m["counters"]["closest_queries"], name
@@ -121,13 +121,14 @@ def test_result_is_independent_of_the_bvh_shape(frames, leaf_max):
 
 
 def test_schedules_and_scene_placements_are_bit_identical():
-    """wavefront vs tree kernel, wave-wide vs per-lane BVH walk, scene read from its LDS copy vs from
-    HBM/L2: same bits, same ray counts."""
+    """tile vs wavefront vs tree schedule, wave-wide vs per-lane BVH walk, scene read from its LDS copy vs
+    from HBM/L2: same bits, same ray counts."""
     for name in ("c2_mount_low_256x144_d4_bvh", "c4_mount_low_96_d6_spp2", "balls_box_128_d4_bvh", "dof_64_d4_spp4",
                  "balls_medium_128_d4_none"):
         a = gpu_render(CASES[name], counters=True, wavefront=True)
         for kw in (dict(tree=True), dict(no_lds=True), dict(tree=True, no_lds=True), dict(no_packet=True),
-                   dict(no_packet=True, no_lds=True)):
+                   dict(no_packet=True, no_lds=True), dict(tile=True), dict(tile=True, no_lds=True),
+                   dict(tile=True, no_packet=True), dict(tile=True, no_packet=True, no_lds=True), dict(wavefront=True, no_lds=True)):
             b = gpu_render(CASES[name], counters=True, **kw)
             assert np.array_equal(a["rgb8"], b["rgb8"]) and np.array_equal(a["hit_id"], b["hit_id"]), (name, kw)
             assert np.array_equal(a["rgb32f"].view(np.uint32), b["rgb32f"].view(np.uint32)), (name, kw)
@@ -140,12 +141,32 @@ def test_wavefront_bands_do_not_change_the_image():
     m = CASES["c2_mount_low_256x144_d4_bvh"]
     hs = P.HostScene(scene_path(m["scene"])); hs.set_resolution(*m["res"])
     ds = P.DeviceScene.from_host(hs)
-    full = ds.render(hs.camera(), accel=2)
-    ds.set_tuning(workspace_mib=1)          # 1 MiB: a few tile rows per band
-    banded = ds.render(hs.camera(), accel=2)
+    full = ds.render(hs.camera(), accel=2, wavefront=True)
+    ds.set_tuning(workspace_mib=8)          # a row of 16x16 tiles needs 3.2 MB at depth 4: two tile rows per band
+    banded = ds.render(hs.camera(), accel=2, wavefront=True)
+    assert ds.last_schedule() == "wavefront"
     assert np.array_equal(full["rgb8"], banded["rgb8"]) and np.array_equal(full["hit_id"], banded["hit_id"])
     assert np.array_equal(full["rgb32f"].view(np.uint32), banded["rgb32f"].view(np.uint32))
     ds.close()
+
+
+def test_grid_mode_full_size_against_live_oracle():
+    """mount_low 1920x1080 depth 4 in GRID mode (accel 1): the reference's grid accepts hits per cell, which at this
+    size differs from brute force / BVH mode in one pixel; the device walks the same grid, so
+    hit ids, ray counts and colours match the oracle's GRID render, including that pixel."""
+    m = dict(scene="mount_low", res=[1920, 1080], accel=1, spp=0, max_depth=4, seed=0)
+    sc = O.Scene(scene_path("mount_low")); sc.set_resolution(1920, 1080)
+    ref = sc.render(max_depth=4, accel=1, threads=8)
+    bvh = sc.render(max_depth=4, accel=2, threads=8)
+    n_diff = int((ref["rgb8"] != bvh["rgb8"]).any(axis=2).sum())
+    assert n_diff >= 1, "GRID and BVH mode are expected to differ at this size"
+    for kw in (dict(tile=True), dict(wavefront=True), dict(tree=True)):
+        out = gpu_render(m, counters=True, **kw)
+        compare(out, ref["rgb8"], ref["rgb32f"], ref["hit_id"], "grid-1080p")
+        assert out["counters"]["rays"] == ref["counters"]["rays"]
+        where = (ref["rgb8"] != bvh["rgb8"]).any(axis=2)
+        assert np.array_equal(out["rgb8"][where], ref["rgb8"][where])
+    print("grid mode: %d px differ from BVH mode, all reproduced" % n_diff)
 
 
 def test_config2_full_size_against_live_oracle():
@@ -226,7 +247,7 @@ def test_sample_frames_never_write_past_the_image_in_device_buffers():
     dev8 = torch.full((H + pad, W, 3), 0xA5, dtype=torch.uint8, device="cuda")
     devf = torch.full((H + pad, W, 3), -7.0, dtype=torch.float32, device="cuda")
     devh = torch.full((H + pad, W), -99, dtype=torch.int32, device="cuda")
-    for kw in (dict(wavefront=True), dict(tree=True)):
+    for kw in (dict(tile=True), dict(wavefront=True), dict(tree=True)):
         ds.render_device(cam, rgb8_ptr=dev8.data_ptr(), rgb32f_ptr=devf.data_ptr(), hit_ptr=devh.data_ptr(),
                          max_depth=4, accel=2, spp=2, samples=smp, **kw)
         ds.sync()
@@ -234,6 +255,55 @@ def test_sample_frames_never_write_past_the_image_in_device_buffers():
         assert np.array_equal(dev8[:H].cpu().numpy(), ref["rgb8"])
         assert np.array_equal(devf[:H].cpu().numpy().view(np.uint32), ref["rgb32f"].view(np.uint32))
         assert np.array_equal(devh[:H].cpu().numpy(), ref["hit_id"])
+    ds.close()
+
+
+def test_small_workspace_budget_falls_back_from_the_tile_schedule():
+    """The tile schedule needs one private slot per resident workgroup; when the budget holds too few it is
+    the wavefront schedule (in bands) that renders -- same bits."""
+    m = CASES["c2_mount_low_256x144_d4_bvh"]
+    hs = P.HostScene(scene_path(m["scene"])); hs.set_resolution(*m["res"])
+    ds = P.DeviceScene.from_host(hs)
+    a = ds.render(hs.camera(), accel=2, tile=True)
+    assert ds.last_schedule() == "tile"
+    ds.set_tuning(workspace_mib=8)          # a depth-4 slot is 0.2 MB: only 41 workgroups would get one
+    b = ds.render(hs.camera(), accel=2, tile=True)
+    assert ds.last_schedule() == "wavefront"
+    ds.set_tuning(workspace_mib=1)          # ... and not even one band of the wavefront queues fits 1 MiB
+    c = ds.render(hs.camera(), accel=2, tile=True)
+    assert ds.last_schedule() == "tree" and np.array_equal(a["rgb32f"].view(np.uint32), c["rgb32f"].view(np.uint32))
+    assert np.array_equal(a["rgb32f"].view(np.uint32), b["rgb32f"].view(np.uint32)) and np.array_equal(a["hit_id"], b["hit_id"])
+    ds.close()
+
+
+@pytest.mark.parametrize("schedule", ["tile", "wavefront"])
+def test_captured_frame_replays_identically(schedule):
+    """p3d_render keeps no per-frame state on the host: a frame captured into a HIP graph can be replayed any
+    number of times (tile schedule: the kernel re-arms its own tile counter; wavefront: the counter memset is
+    part of the captured stream)."""
+    torch = pytest.importorskip("torch")
+    hs = P.HostScene(scene_path("balls_low"))
+    hs.set_resolution(320, 200)
+    cam = hs.camera()
+    ds = P.DeviceScene.from_host(hs)
+    ref = ds.render(cam, accel=2, max_depth=3)
+    for kw in (dict([(schedule, True)]),):
+        out8 = torch.zeros((200, 320, 3), dtype=torch.uint8, device="cuda")
+        ds.render_device(cam, rgb8_ptr=out8.data_ptr(), accel=2, max_depth=3, **kw)      # sizes every workspace
+        ds.sync()
+        side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            ds.set_stream(torch.cuda.current_stream().cuda_stream)
+            ds.render_device(cam, rgb8_ptr=out8.data_ptr(), accel=2, max_depth=3, **kw)
+        ds.set_stream(0)
+        for k in range(3):                       # an odd number of replays of ONE graph
+            out8.fill_(0)
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(out8.cpu().numpy(), ref["rgb8"]), (kw, k)
+        eager = ds.render(cam, accel=2, max_depth=3, counters=True, **kw)                 # and eager frames still work
+        assert np.array_equal(eager["rgb8"], ref["rgb8"]) and eager["counters"]["pixels"] == 320 * 200
     ds.close()
 
 

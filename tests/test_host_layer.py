@@ -60,6 +60,19 @@ def test_library_links_rccl_and_the_gather_rejects_bad_arguments():
             raise P.P3DError("GPU present: the hardware path is covered by tests/test_gpu_multigpu.py")
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_host_grid_is_the_reference_grid(name):
+    """csrc/grid_builder.cpp (what GRID mode walks on the device) == Grid::Build: the oracle's restatement is
+    bit-checked against the reference's own grid.o in tests/test_oracle_vs_ref.py, so equality with it is
+    equality with the reference: same dimensions, same population in every cell."""
+    hs = P.HostScene(scene_path(name))
+    dims, counts = api.host_grid(hs.desc())
+    sc = O.Scene(scene_path(name))
+    d_o, c_o = sc.refgrid_dims(with_cells=True)
+    assert np.array_equal(dims, d_o)
+    assert np.array_equal(counts, c_o.astype(np.uint32))
+
+
 def test_missing_extension_fails_loudly(monkeypatch):
     monkeypatch.setattr(api, "_lib", None)
     monkeypatch.setattr(api, "LIB_PATH", "/nonexistent/libp3d_hip.so")

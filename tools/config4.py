@@ -19,13 +19,15 @@ out = torch.zeros((res, res, 3), dtype=torch.uint8, device="cuda")
 kw = dict(max_depth=6, accel=P.ACCEL_BVH, spp=2, samples=samples)
 ds.render_device(cam, rgb8_ptr=out.data_ptr(), counters=True, **kw)
 c = ds.counters(); print("counters", c)
-for tree in (False, True):
-    for _ in range(1): ds.render_device(cam, rgb8_ptr=out.data_ptr(), tree=tree, wavefront=not tree, **kw)
+dev_samples = torch.from_numpy(samples).cuda()            # uploaded once (P3D_FLAG_DEVICE_SAMPLES)
+kwd = dict(max_depth=6, accel=P.ACCEL_BVH, spp=2, samples_ptr=dev_samples.data_ptr())
+for sched in ("tile", "wavefront", "tree"):
+    for _ in range(1): ds.render_device(cam, rgb8_ptr=out.data_ptr(), **{sched: True}, **kwd)
     ds.sync()
     n = 3
     t = time.perf_counter()
-    for _ in range(n): ds.render_device(cam, rgb8_ptr=out.data_ptr(), tree=tree, wavefront=not tree, profile=True, **kw)
+    for _ in range(n): ds.render_device(cam, rgb8_ptr=out.data_ptr(), profile=True, **{sched: True}, **kwd)
     f_ms, k_ms = ds.profile(); ds.sync()
     wall = (time.perf_counter() - t) / n * 1e3
-    print("%s: device %.2f ms/frame (wall incl. %.0f MB sample upload %.1f ms)  %.1f Mrays/s  checksum %d" % (
-        "tree" if tree else "wavefront", f_ms, samples.nbytes / 1e6, wall, c["rays"] / f_ms / 1e3, int(out.sum().item())))
+    print("%s: device %.2f ms/frame (wall %.1f ms, samples resident)  %.1f Mrays/s  checksum %d" % (
+        sched, f_ms, wall, c["rays"] / f_ms / 1e3, int(out.sum().item())))

@@ -51,13 +51,14 @@ ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=a.depth, accel=a.accel,
 c = ds.counters()
 print("counters", c)
 ref = None
-for tree in ([False, True] if not a.tree else [True]):
+for sched in (["tile", "wavefront", "tree"] if not a.tree else ["tree"]):
+  tree = sched == "tree"
   for no_lds, no_packet in ((False, False), (False, True), (True, False), (True, True)):
    if tree and not no_packet: continue
    for occ in [int(v) for v in a.occ.split(",")]:
     for ch in [int(v) for v in a.chunks.split(",")]:
         ds.set_tuning(xcd_chunk=ch, waves_per_simd=occ)
-        kw = dict(max_depth=a.depth, accel=a.accel, tree=tree, wavefront=not tree, no_lds=no_lds, no_packet=no_packet)
+        kw = dict(max_depth=a.depth, accel=a.accel, no_lds=no_lds, no_packet=no_packet, **{sched: True})
         for _ in range(5):
             ds.render_device(cam, rgb8_ptr=buf.data_ptr(), **kw)
         ds.timer_begin()
@@ -68,5 +69,5 @@ for tree in ([False, True] if not a.tree else [True]):
         if ref is None:
             ref = img
         print("%s %s occ %d xcd_chunk %6d: %.4f ms/frame  %.1f Mrays/s  alg %.0f GB/s  same_image=%s" % (
-            "tree     " if tree else "wavefront", ("hbm" if no_lds else "lds") + ("/lane  " if no_packet else "/packet"), occ, ch, ms, c["rays"] / ms / 1e3,
+            "%-9s" % sched, ("hbm" if no_lds else "lds") + ("/lane  " if no_packet else "/packet"), occ, ch, ms, c["rays"] / ms / 1e3,
             (c["algorithmic_bytes"] + 3 * c["pixels"]) / ms / 1e6, np.array_equal(img, ref)))

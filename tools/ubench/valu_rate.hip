@@ -46,6 +46,34 @@ __global__ __launch_bounds__(1024) void k(float* out, unsigned long long* cyc, f
                 asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n"
                              "v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (KIND == 8) {   // 8 independent s_add_u32 / s_mul_i32 (scalar ALU)
+                unsigned s0 = it, s1 = it + 1, s2 = it + 2, s3 = it + 3;
+                asm volatile("s_add_u32 %0, %0, 3\n s_add_u32 %1, %1, 5\n s_add_u32 %2, %2, 7\n s_add_u32 %3, %3, 9\n"
+                             "s_add_u32 %0, %0, 3\n s_add_u32 %1, %1, 5\n s_add_u32 %2, %2, 7\n s_add_u32 %3, %3, 9\n"
+                             : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+                a0 += (float)(s0 + s1 + s2 + s3) * 1e-30f;
+            } else if (KIND == 9) {   // 4 x (v_cmp_lt_f32 vcc ; v_cndmask vcc): the compare/select pairs of the hit tests
+                asm volatile("v_cmp_lt_f32 vcc, %0, %4\n v_cndmask_b32 %0, %0, %4, vcc\n v_cmp_lt_f32 vcc, %1, %4\n v_cndmask_b32 %1, %1, %4, vcc\n"
+                             "v_cmp_lt_f32 vcc, %2, %4\n v_cndmask_b32 %2, %2, %4, vcc\n v_cmp_lt_f32 vcc, %3, %4\n v_cndmask_b32 %3, %3, %4, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m) : "vcc");
+            } else if (KIND == 10) {  // 4 x (v_cmp -> s_and_saveexec -> restore): a divergent `if` without a branch
+                asm volatile("v_cmp_lt_f32 vcc, %0, %4\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %0, %0, %4\n s_mov_b64 exec, s[20:21]\n"
+                             "v_cmp_lt_f32 vcc, %1, %4\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %1, %1, %4\n s_mov_b64 exec, s[20:21]\n"
+                             "v_cmp_lt_f32 vcc, %2, %4\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %2, %2, %4\n s_mov_b64 exec, s[20:21]\n"
+                             "v_cmp_lt_f32 vcc, %3, %4\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %3, %3, %4\n s_mov_b64 exec, s[20:21]\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m) : "vcc", "s20", "s21");
+            } else if (KIND == 11) {  // 8 v_readfirstlane_b32 (VALU -> SGPR)
+                unsigned t0, t1, t2, t3;
+                asm volatile("v_readfirstlane_b32 %0, %4\n v_readfirstlane_b32 %1, %5\n v_readfirstlane_b32 %2, %6\n v_readfirstlane_b32 %3, %7\n"
+                             "v_readfirstlane_b32 %0, %4\n v_readfirstlane_b32 %1, %5\n v_readfirstlane_b32 %2, %6\n v_readfirstlane_b32 %3, %7\n"
+                             : "=s"(t0), "=s"(t1), "=s"(t2), "=s"(t3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+                a4 += (float)(t0 ^ t1 ^ t2 ^ t3) * 1e-30f;
+            } else if (KIND == 12) {  // LDS round trip: dependent ds_read_b32 chain (address from the previous read)
+                extern __shared__ unsigned lds[];
+                unsigned idx = threadIdx.x & 255;
+                lds[idx] = idx;
+                for (int q = 0; q < 8; q++) idx = lds[idx & 255];
+                a5 += (float)idx * 1e-30f;
             } else if (KIND == 7) {   // 8 v_cndmask
                 asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
                              "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
@@ -64,8 +92,8 @@ static void run(const char* name, int insts_per_rep8) {
     hipMalloc(&out, 256 * 1024 * 4 * 8); hipMalloc(&cyc, 256 * 16 * 8 * 8);
     for (int waves_per_simd : {1, 2, 4}) {
         int threads = 64 * 4 * waves_per_simd;    // one block per CU
-        hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, 1.0f);
-        hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 0, 0, out, cyc, 1.0f);
+        hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 1024, 0, out, cyc, 1.0f);
+        hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(threads), 1024, 0, out, cyc, 1.0f);
         hipDeviceSynchronize();
         std::vector<unsigned long long> h(256 * threads / 64);
         hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
@@ -87,6 +115,11 @@ int main() {
     run<4>("IEEE fdiv x8 (expansion)", 8);
     run<5>("IEEE sqrt x8 (expansion)", 8);
     run<6>("v_mov_b32 x8", 8);
-    run<7>("v_cndmask x8", 8);
+    run<7>("v_cndmask x8 (vcc stale)", 8);
+    run<8>("s_add_u32 x8 (+2 valu)", 8);
+    run<9>("v_cmp+v_cndmask x4 pairs", 8);
+    run<10>("cmp/saveexec/add/restore x4", 16);
+    run<11>("v_readfirstlane x8 (+2 valu)", 8);
+    run<12>("dependent ds_read_b32 x8", 8);
     return 0;
 }

@@ -17,6 +17,8 @@ FLAG_NO_LDS_SCENE = 4
 FLAG_NO_PACKET = 8
 FLAG_PROFILE = 16
 FLAG_WAVEFRONT = 32
+FLAG_TILE_KERNEL = 64
+FLAG_DEVICE_SAMPLES = 128
 FEATURE_SOFT_SHADOW, FEATURE_FUZZY_REFLECTION = 1, 2
 
 
@@ -81,7 +83,7 @@ C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_s
                  "p3d_get_counters", "p3d_get_profile", "p3d_last_schedule", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end", "p3d_deinterleave_frames",
                  "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_set_stamps",
                  "p3d_comm_unique_id", "p3d_comm_create", "p3d_comm_create_all", "p3d_comm_destroy", "p3d_comm_info",
-                 "p3d_gather", "p3d_gather_all", "p3d_device_alloc", "p3d_device_free", "p3d_download"]
+                 "p3d_gather", "p3d_gather_all", "p3d_device_alloc", "p3d_device_free", "p3d_upload", "p3d_download"]
 
 
 def build_native(verbose=False):
@@ -142,6 +144,7 @@ def lib():
     L.p3d_device_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
     L.p3d_device_free.argtypes = [C.c_void_p, C.c_void_p]
     L.p3d_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.p3d_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.p3d_pt_reduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.p3d_debug_intersect.argtypes = [C.c_int, C.c_uint32] + [C.c_void_p] * 7
     # host shim
@@ -347,10 +350,10 @@ class DeviceScene:
         return f.value, k.value
 
     def last_schedule(self):
-        """'wavefront' or 'tree': the kernel schedule of the most recent render."""
+        """'wavefront', 'tree' or 'tile': the kernel schedule of the most recent render."""
         v = C.c_int32()
         _check(lib().p3d_last_schedule(self.h, C.byref(v)), "p3d_last_schedule")
-        return "tree" if v.value else "wavefront"
+        return ("wavefront", "tree", "tile")[v.value]
 
     def debug_set_stamps(self, ptr):
         _check(lib().p3d_debug_set_stamps(self.h, C.c_void_p(ptr or None)), "p3d_debug_set_stamps")
@@ -360,18 +363,20 @@ class DeviceScene:
         _check(lib().p3d_get_counters(self.h, C.byref(c)), "p3d_get_counters")
         return c.as_dict()
 
-    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0):
+    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0):
         p = RenderParams()
         p.max_depth, p.accel, p.spp = int(max_depth), int(accel), int(spp)
         p.samples = samples.ctypes.data_as(C.POINTER(C.c_float)) if samples is not None else None
+        if samples_ptr:                      # sample array already on the device (uploaded once by the caller)
+            p.samples = C.cast(C.c_void_p(int(samples_ptr)), C.POINTER(C.c_float))
         p.row_block, p.rank, p.world = int(row_block), int(rank), int(world)
         p.features = (FEATURE_SOFT_SHADOW if soft_shadow else 0) | (FEATURE_FUZZY_REFLECTION if fuzzy_reflection else 0)
         p.seed = int(seed) & 0xFFFFFFFF
-        p.flags = (FLAG_COUNTERS if counters else 0) | (FLAG_TREE_KERNEL if tree else 0) | (FLAG_NO_LDS_SCENE if no_lds else 0) | (FLAG_NO_PACKET if no_packet else 0) | (FLAG_PROFILE if profile else 0) | (FLAG_WAVEFRONT if wavefront else 0)
+        p.flags = (FLAG_COUNTERS if counters else 0) | (FLAG_TREE_KERNEL if tree else 0) | (FLAG_NO_LDS_SCENE if no_lds else 0) | (FLAG_NO_PACKET if no_packet else 0) | (FLAG_PROFILE if profile else 0) | (FLAG_WAVEFRONT if wavefront else 0) | (FLAG_TILE_KERNEL if tile else 0) | (FLAG_DEVICE_SAMPLES if samples_ptr else 0)
         return p
 
     def render(self, cam, max_depth=4, accel=ACCEL_BVH, spp=0, samples=None, rank=0, world=1, row_block=16,
-               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0):
+               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False):
         """Render into host numpy arrays (rows: res_y for world==1, local_rows otherwise)."""
         rows = cam.res_y if world == 1 else local_rows(cam.res_y, row_block, world)
         rgb8 = np.zeros((rows, cam.res_x, 3), np.uint8)
@@ -379,7 +384,7 @@ class DeviceScene:
         hid = np.full((rows, cam.res_x), -2, np.int32) if want_hit else None
         if samples is not None:
             samples = np.ascontiguousarray(samples, np.float32)
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile, wavefront, soft_shadow, fuzzy_reflection, seed)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile)
         o = Outputs(rgb8.ctypes.data, f32.ctypes.data if want_f32 else None,
                     hid.ctypes.data if want_hit else None, 0)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
@@ -389,9 +394,10 @@ class DeviceScene:
         return out
 
     def render_device(self, cam, rgb8_ptr=0, rgb32f_ptr=0, hit_ptr=0, max_depth=4, accel=ACCEL_BVH, spp=0,
-                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0):
-        """Enqueue one frame into caller-owned DEVICE buffers (raw pointers); asynchronous."""
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile, wavefront, soft_shadow, fuzzy_reflection, seed)
+                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0):
+        """Enqueue one frame into caller-owned DEVICE buffers (raw pointers); asynchronous.  samples_ptr: the
+        spp > 0 sample array as a device pointer (uploaded once by the caller) instead of `samples`."""
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, samples_ptr)
         o = Outputs(rgb8_ptr or None, rgb32f_ptr or None, hit_ptr or None, 1)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
 
@@ -513,6 +519,18 @@ def host_bvh(desc, leaf_max=0):
     lib().p3dh_bvh_free(h)
     return {"nodes": nodes, "refs": refs, "n_leaves": int(info[2]), "max_depth": int(info[3]),
             "n_prims": int(info[4])}
+
+
+def host_grid(desc):
+    """Host-only build of the reference's uniform grid (no GPU): (dims[3], per-cell populations)."""
+    L = lib()
+    L.p3dh_grid_build.restype = C.c_int64
+    L.p3dh_grid_build.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int32), C.c_void_p, C.c_uint64]
+    dims = (C.c_int32 * 3)()
+    n = L.p3dh_grid_build(C.byref(desc), dims, None, 0)
+    counts = np.zeros(n, np.uint32)
+    L.p3dh_grid_build(C.byref(desc), dims, counts.ctypes.data, n)
+    return np.array(list(dims), np.int32), counts
 
 
 class PathTracer:

@@ -9,6 +9,7 @@
 
 #include "../bvh_builder.h"
 #include "../scene_flatten.h"
+#include "../grid_builder.h"
 #include "p3d_scene.h"
 
 using namespace p3d_host;
@@ -80,6 +81,19 @@ void p3dh_bvh_info(const p3dh_bvh* b, uint32_t* out) {
 void p3dh_bvh_dump(const p3dh_bvh* b, uint32_t* nodes16, uint32_t* refs) {
     memcpy(nodes16, b->nodes.data(), b->nodes.size() * sizeof(p3d::NodePair));
     memcpy(refs, b->refs.data(), b->refs.size() * sizeof(uint32_t));
+}
+
+// ---- host-only grid build (the reference's Grid::Build layout, csrc/grid_builder.cpp), for tests without a GPU
+// dims[3]; counts: cells' populations (nx*ny*nz) or NULL; returns the number of cells, or -1
+int64_t p3dh_grid_build(const p3d_scene_desc* d, int32_t* dims, uint32_t* counts, uint64_t counts_cap) {
+    std::vector<p3d::GridPrim> prims;
+    p3d::grid_prims_from_desc(*d, prims);
+    p3d::GridHost g;
+    p3d::build_grid(prims, g);
+    dims[0] = g.n[0]; dims[1] = g.n[1]; dims[2] = g.n[2];
+    const size_t cells = g.cell_start.size() - 1;
+    if (counts) for (size_t c = 0; c < cells && c < counts_cap; c++) counts[c] = g.cell_start[c + 1] - g.cell_start[c];
+    return (int64_t)cells;
 }
 
 }  // extern "C"

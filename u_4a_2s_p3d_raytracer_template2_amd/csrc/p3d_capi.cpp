@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "bvh_builder.h"
+#include "grid_builder.h"
 #include "p3d_device_types.h"
 #include "scene_flatten.h"
 
@@ -20,10 +21,15 @@ namespace p3d {
 size_t tree_kernel_lds_bytes(const LaunchParams& P, bool lds);
 size_t wavefront_lds_bytes(const LaunchParams& P, bool lds);
 hipError_t launch_tree(const LaunchParams& P, bool count, bool lds, int occ, hipStream_t stream);
-hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, bool packet, int occ, hipStream_t stream);
-hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, bool packet, int occ, unsigned waves,
+hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, int walk, int occ, hipStream_t stream);
+hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, int walk, int occ, unsigned waves,
                                hipStream_t stream);
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream);
+hipError_t launch_clear_words(uint32_t* p, uint32_t n, hipStream_t stream);
+hipError_t wf_resident_waves(const LaunchParams& P, bool primary, bool count, bool lds, int walk, int occ, unsigned* waves);
+size_t tile_kernel_lds_bytes(const LaunchParams& P, bool lds);
+hipError_t tile_kernel_resident_blocks(const LaunchParams& P, bool count, bool lds, int walk, int occ, int* blocks);
+hipError_t launch_wf_tile(const LaunchParams& P, bool count, bool lds, int walk, int occ, unsigned blocks, hipStream_t stream);
 hipError_t launch_raygen_table(float* fx, float* fy, int res_x, int res_y, hipStream_t stream);
 hipError_t prepare_kernels(size_t max_lds);
 hipError_t launch_sum_samples(const LaunchParams& P, size_t first_px, size_t n_px, hipStream_t stream);
@@ -98,12 +104,15 @@ struct p3d_scene {
     DevBuf<PlaneRec> planes;
     DevBuf<PrimMeta> plane_meta;
     DevBuf<LightRec> lights;
+    // GRID mode (accel 1): the reference's uniform grid, built from grid_src on the first GRID frame
+    std::vector<GridPrim> grid_src;
+    DevBuf<uint32_t> grid_cells, grid_items;
+    GridHost grid_info; bool grid_ready = false;
     DevBuf<LightRec> soft_lights;          // 16 sub-lights per light, built on first use (SOFT_SHADOW, spp == 0)
     std::vector<LightRec> host_lights;
     size_t lds_scene_limit = 24 * 1024;  // blobs up to this size are rendered from an LDS copy
     int last_schedule = -1;
     bool unit_rays_only = false;         // built with cull_never_hit: cannot serve un-normalised (NONE-mode) shadow rays
-    size_t tree_blob_limit = (size_t)2 << 20;   // scenes above this pick their schedule by measurement
     uint32_t packet_node_limit = 64;     // trees up to this many node pairs use the wave-wide walk
     float bg[3] = {0, 0, 0};
     uint32_t n_lights = 0, n_materials = 0;
@@ -115,10 +124,7 @@ struct p3d_scene {
     // time, each on its own stream with its own queues: the latency-bound deep levels and launch tails
     // of one pass fill with another pass's work, like independent frames do.  Lane 0 is the scene's stream.
     struct Workspace {
-        RawBuf rays[kMaxDepth + 2], nodes[kMaxDepth + 2], counts;
-        // counts holds TWO sets of counters: a pass uses set `parity` and its level-1 launch clears the
-        // other one for the pass after it, so only the first pass over a workspace needs a memset
-        int parity = 0; bool clean[2] = {false, false};
+        RawBuf rays[kMaxDepth + 2], nodes[kMaxDepth + 2], counts;   // counts: cleared by a kernel in front of every pass
         RawBuf rng[kMaxDepth + 2];           // random-stream keys of the queued rays (stochastic features)
         void release() {
             for (auto& b : rays) b.release();
@@ -128,6 +134,11 @@ struct p3d_scene {
         }
     } ws[kLanes];
     RawBuf wf_planes;                        // [sample][local px][3] clamped sample colours (spp > 0)
+    // tile schedule: (resident workgroups) x (one 16x16 tile's worst-case queues), and the tile counter + exit
+    // ticket the kernel re-arms itself (zeroed once, at allocation)
+    RawBuf tile_ws, tile_ctrl;
+    struct { uint32_t key = 0xFFFFFFFFu; size_t lds = 0; int blocks = 0; } tile_occ;   // cached occupancy query
+    struct { uint32_t key = 0xFFFFFFFFu; uint32_t stack = 0; unsigned waves = 0, primary_waves = 0; } wf_occ;                 // ... of the deeper-level kernel
     hipStream_t lane_stream[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     // worst-case queues a frame may allocate; only what a frame needs is ever allocated.  64 GiB holds
@@ -137,14 +148,13 @@ struct p3d_scene {
     bool counters_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_prof[4] = {nullptr, nullptr, nullptr, nullptr};   // frame begin/end, dominant kernel begin/end
-    // Schedule choice for scenes above tree_blob_limit: measured, not guessed.  The first frame of a
-    // (resolution, depth, accel, spp, shard) configuration runs the wavefront schedule and the second
-    // the tree schedule, each bracketed by HIP events; later frames use the faster one.  Both produce
-    // identical bits, so the choice is invisible in the output.
+    // Schedule choice: measured, not guessed.  The first frames of a (resolution, depth, accel, spp, shard, flags)
+    // configuration run every available schedule twice, the second time bracketed by HIP events; later frames
+    // use the fastest one.  All produce identical bits, so the choice is invisible in the output.
     struct SchedulePick {
-        int32_t key[7] = {0, 0, 0, -1, -1, 0, 0};
-        float ms[2] = {-1.0f, -1.0f};
-        int pending = -1;
+        int32_t key[8] = {0, 0, 0, -1, -1, 0, 0, 0};
+        float ms[3] = {-1.0f, -1.0f, -1.0f};     // wavefront, tree, tile
+        int pending = -1, step = 0, best = 2;
     } pick;
     hipEvent_t ev_pick[2] = {nullptr, nullptr};
     bool profile_valid = false;
@@ -287,6 +297,7 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     if ((e = s->plane_meta.upload(plane_meta)) != hipSuccess) return bail(e, "upload plane meta");
     if ((e = s->lights.upload(lights)) != hipSuccess) return bail(e, "upload lights");
     s->host_lights = lights;
+    grid_prims_from_desc(*d, s->grid_src);
     if ((e = hipMalloc((void**)&s->d_counters, sizeof(DeviceCounters))) != hipSuccess) return bail(e, "alloc counters");
     if ((e = hipMemset(s->d_counters, 0, sizeof(DeviceCounters))) != hipSuccess) return bail(e, "clear counters");
     memcpy(s->bg, d->background, sizeof s->bg);
@@ -306,10 +317,11 @@ int p3d_scene_destroy(p3d_scene* s) {
     if (!s) return P3D_OK;
     (void)hipSetDevice(s->device);
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
+    s->grid_cells.release(); s->grid_items.release();
     s->blob.release(); s->planes.release(); s->plane_meta.release(); s->lights.release(); s->soft_lights.release();
     s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release(); s->ray_tab.release();
     for (auto& w : s->ws) w.release();
-    s->wf_planes.release();
+    s->wf_planes.release(); s->tile_ws.release(); s->tile_ctrl.release();
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     for (int i = 1; i < kLanes; i++) {
         if (s->ev_join[i]) (void)hipEventDestroy(s->ev_join[i]);
@@ -341,7 +353,7 @@ int p3d_set_tuning(p3d_scene* s, int32_t xcd_chunk, int32_t workspace_mib, int32
     if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
     if (xcd_chunk < 0 || xcd_chunk > (1 << 20)) return fail(P3D_ERR_ARG, "xcd_chunk must be >= 0");
     if (workspace_mib < 0) return fail(P3D_ERR_ARG, "workspace_mib must be >= 0");
-    s->pick.ms[0] = s->pick.ms[1] = -1.0f; s->pick.pending = -1;      // tuning changes what the schedules cost
+    s->pick.key[0] = 0;                                                // tuning changes what the schedules cost: measure again
     if (xcd_chunk) s->xcd_chunk = xcd_chunk;
     if (workspace_mib) s->workspace_budget = (size_t)workspace_mib << 20;
     if (waves_per_simd >= 0) {
@@ -362,20 +374,22 @@ size_t wavefront_bytes_per_pixel(int D) {
     return b;
 }
 
-constexpr int kShards = 64;   // queue shards (power of two); spreads the slot-allocation atomics
+constexpr int kShards = 64;   // queue shards; spreads the slot-allocation atomics. == the wave size: the deeper-level
+                              // kernel holds one shard's count per lane (wf_secondary_kernel)
 
 // One sample pass over one band of tile rows, level by level (see p3d_kernels.hip).
 // shard_px = pixels a shard can own in this band (worst case), so level l holds at most
 // shard_px << (l-1) rays / nodes per shard.
 int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t stream, LaunchParams P, bool count, bool lds,
-                       bool packet, size_t shard_px, bool profile) {
+                       int walk, size_t shard_px, bool profile) {
     const int D = P.max_depth;
     const size_t n_counts = (size_t)2 * (kMaxDepth + 2) * kShards;
-    const int par = ws.parity;
-    uint32_t* counts = (uint32_t*)ws.counts.p + (size_t)par * n_counts;    // [level][shard] ray counts, then node counts
-    if (!ws.clean[par]) HIP_TRY(hipMemsetAsync(counts, 0, n_counts * sizeof(uint32_t), stream));
-    P.wf_clear = (uint32_t*)ws.counts.p + (size_t)(1 - par) * n_counts; P.wf_clear_words = (uint32_t)n_counts;
-    ws.clean[par] = false;
+    uint32_t* counts = (uint32_t*)ws.counts.p;                              // [level][shard] ray counts, then node counts
+    // cleared on the stream in front of every pass: nothing about a frame lives in host state, so a captured
+    // frame can be replayed any number of times (a kernel, not hipMemsetAsync: a captured memset node of this
+    // buffer faulted on replay under ROCm 7.2 -- "write access to a read-only page")
+    HIP_TRY(launch_clear_words(counts, (uint32_t)n_counts, stream));
+    P.wf_clear = nullptr; P.wf_clear_words = 0;
     auto rays = [&](int l) { return (l >= 2 && l <= D) ? (RayRec*)ws.rays[l].p : nullptr; };
     auto nodes = [&](int l) { return (l >= 1 && l <= D - 1) ? (NodeRec*)ws.nodes[l].p : nullptr; };
     auto qcount = [&](int l) { return counts + (size_t)l * kShards; };
@@ -389,9 +403,16 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
     P.wf_rng_in = nullptr; P.wf_rng_out = rng(2);
     P.wf_nodes_parent = nullptr; P.wf_ncap_parent = 0;
     P.wf_nodes_self = nodes(1); P.wf_ncount_self = ncount(1); P.wf_ncap_self = cap(1);
+    {   // persistent grids: as many waves as can be resident (cached occupancy queries)
+        const uint32_t okey = (count ? 1u : 0u) | (lds ? 2u : 0u) | ((uint32_t)walk << 2) | (P.features ? 16u : 0u) | ((uint32_t)s->occupancy << 5);
+        if (s->wf_occ.key != okey || s->wf_occ.stack != P.trav_stack_dwords) {
+            HIP_TRY(wf_resident_waves(P, false, count, lds, walk, s->occupancy, &s->wf_occ.waves));
+            s->wf_occ.key = okey; s->wf_occ.stack = P.trav_stack_dwords;
+        }
+    }
+    const unsigned resident_waves = s->wf_occ.waves;
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], stream));
-    HIP_TRY(launch_wf_primary(P, count, lds, packet, s->occupancy, stream));
-    ws.clean[1 - par] = true; ws.parity = 1 - par;         // the launch that clears the other set is enqueued
+    HIP_TRY(launch_wf_primary(P, count, lds, walk, s->occupancy, stream));
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], stream));
     for (int l = 2; l <= D; l++) {
         P.wf_level = l;
@@ -401,9 +422,10 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
         P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = cap(l - 1);
         P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
         size_t total = (size_t)cap(l) * kShards;
-        unsigned waves = (unsigned)std::min<size_t>((total + 63) / 64, lds ? kPersistentWaves : kPersistentWavesNarrow);
+        // LDS scenes: as many waves as can be resident (the kernel numbers its batches through all shards)
+        unsigned waves = (unsigned)std::min<size_t>((total + 63) / 64, lds ? resident_waves : kPersistentWavesNarrow);
         waves = std::max<unsigned>(kShards * 4, (waves / (kShards * 4)) * (kShards * 4));   // whole workgroups per shard
-        HIP_TRY(launch_wf_secondary(P, count, lds, packet, s->occupancy, waves, stream));
+        HIP_TRY(launch_wf_secondary(P, count, lds, walk, s->occupancy, waves, stream));
     }
     for (int l = D - 1; l >= 1; l--) {
         P.wf_level = l;
@@ -441,8 +463,23 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     // small scenes are rendered from an LDS copy shared by the 4 waves of a 256-thread workgroup
     const bool lds_scene = !(prm->flags & P3D_FLAG_NO_LDS_SCENE) && (size_t)s->blob_quads * 16 <= s->lds_scene_limit;
     P.wg_waves = lds_scene ? 4 : 1;
-    // small trees are walked by the whole wave together (packet walk), large ones per lane
-    const bool packet = !(prm->flags & P3D_FLAG_NO_PACKET) && s->stats.n_nodes <= s->packet_node_limit;
+    // small trees are walked by the whole wave together (packet walk), large ones per lane; GRID mode walks the
+    // reference's uniform grid per lane
+    const bool packet = prm->accel != P3D_ACCEL_GRID && !(prm->flags & P3D_FLAG_NO_PACKET) && s->stats.n_nodes <= s->packet_node_limit;
+    const int walk = prm->accel == P3D_ACCEL_GRID ? 2 : (packet ? 1 : 0);
+    if (prm->accel == P3D_ACCEL_GRID) {
+        if (s->unit_rays_only) return fail(P3D_ERR_STATE, "scene was built with cull_never_hit: GRID mode walks the reference's grid over ALL primitives; use accel BVH");
+        if (!s->grid_ready) {
+            build_grid(s->grid_src, s->grid_info);
+            HIP_TRY(s->grid_cells.upload(s->grid_info.cell_start));
+            HIP_TRY(s->grid_items.upload(s->grid_info.items));
+            s->stats.device_bytes += s->grid_cells.bytes() + s->grid_items.bytes();
+            std::vector<uint32_t>().swap(s->grid_info.cell_start); std::vector<uint32_t>().swap(s->grid_info.items);
+            s->grid_ready = true;
+        }
+        P.grid_cells = s->grid_cells.p; P.grid_items = s->grid_items.p;
+        for (int a = 0; a < 3; a++) { P.grid_n[a] = s->grid_info.n[a]; P.grid_min[a] = s->grid_info.mn[a]; P.grid_max[a] = s->grid_info.mx[a]; }
+    }
     P.n_planes = s->stats.n_planes; P.n_lights = s->n_lights; P.n_materials = s->n_materials;
     P.trav_stack_entries = std::max<uint32_t>(s->stats.max_depth + 1, 2);
     // 8-byte slots for LDS-resident scenes, 6-byte slots for scenes read from HBM (p3d_traverse.h)
@@ -476,11 +513,6 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     P.dbg_stamps = s->dbg_stamps;
     P.wf_min_width = lds_scene ? 64 : 8;
 
-    // Schedule: level-by-level wavefront unless the caller forces one.  Scenes that do not fit an
-    // XCD's L2 have no fixed winner -- 100k-triangle dragon: tree 2.4 ms, wavefront 3.4 ms (a level
-    // launch lasts as long as its slowest ray, four times per frame); 1e6 random primitives: tree
-    // 10.4 ms, wavefront 4.9 ms (every lane's tree is equally deep, so re-compacting rays per level
-    // wins) -- so for them the choice is measured: see SchedulePick.
     // distribution-ray-tracing switches (RT/main.cpp:40-45)
     if (prm->features & ~(P3D_FEATURE_SOFT_SHADOW | P3D_FEATURE_FUZZY_REFLECTION)) return fail(P3D_ERR_ARG, "unknown feature bit");
     if ((prm->features & P3D_FEATURE_SOFT_SHADOW) && prm->spp == 0 && s->n_lights) {
@@ -512,26 +544,41 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     if (prm->features & P3D_FEATURE_FUZZY_REFLECTION) P.features |= kFeatFuzzy;
     P.seed = prm->seed;
     const bool stochastic = P.features != 0;
+    const bool count = (prm->flags & P3D_FLAG_COUNTERS) != 0;
+
+    // ---- schedule.  Three ways to run the same per-node code, bit-identical frames:
+    //   TILE       one launch; a workgroup keeps a 16x16 tile's whole tree to itself (default)
+    //   WAVEFRONT  one launch per tree level over the whole frame + resolve launches
+    //   TREE       one launch; each lane walks its pixel's whole tree
+    // None wins everywhere, so the default is MEASURED per configuration: see SchedulePick below.
+    enum { SCHED_WAVEFRONT = 0, SCHED_TREE = 1, SCHED_TILE = 2 };
+    const uint32_t forced = prm->flags & (P3D_FLAG_TREE_KERNEL | P3D_FLAG_WAVEFRONT | P3D_FLAG_TILE_KERNEL);
+    if (forced & (forced - 1)) return fail(P3D_ERR_ARG, "at most one of P3D_FLAG_TREE_KERNEL / _WAVEFRONT / _TILE_KERNEL");
     if (stochastic && (prm->flags & P3D_FLAG_TREE_KERNEL))
-        return fail(P3D_ERR_ARG, "features with random draws need the wavefront schedule");
-    bool tree_requested = (prm->flags & P3D_FLAG_TREE_KERNEL) != 0;
-    int measuring = -1;                 // schedule this frame is timed as, for the pick below
-    if (!stochastic && !(prm->flags & (P3D_FLAG_TREE_KERNEL | P3D_FLAG_WAVEFRONT)) &&
-        (size_t)s->blob_quads * 16 > s->tree_blob_limit) {
-        p3d_scene::SchedulePick& pk = s->pick;
-        const int32_t key[7] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world};
-        if (memcmp(key, pk.key, sizeof key) != 0) {
-            memcpy(pk.key, key, sizeof key);
-            pk.ms[0] = pk.ms[1] = -1.0f; pk.pending = -1;
+        return fail(P3D_ERR_ARG, "features with random draws need the tile or the wavefront schedule");
+
+    // what the tile schedule needs: its LDS, and one private workspace slot per resident workgroup
+    LaunchParams PT = P;                                   // tile geometry: 16x16 tiles, 4 waves per workgroup
+    PT.wg_waves = 4;
+    PT.tiles_y = P.local_rows / 16; PT.n_tiles = PT.tiles_x * PT.tiles_y;
+    const int D = prm->max_depth;
+    const size_t slot_rays = (size_t)tile_ray_entries(D) * sizeof(RayRec), slot_nodes = (size_t)tile_node_entries(D) * sizeof(NodeRec);
+    const size_t slot_rng = stochastic ? (size_t)tile_ray_entries(D) * sizeof(uint32_t) : 0;
+    const size_t slot_bytes = ((slot_rays + slot_nodes + slot_rng + 255) / 256) * 256 + 256;
+    int tile_blocks = 0;
+    bool tile_ok = tile_kernel_lds_bytes(PT, lds_scene) <= kMaxLdsBytes && D <= 16;
+    if (tile_ok) {
+        const uint32_t okey = (count ? 1u : 0u) | (lds_scene ? 2u : 0u) | ((uint32_t)walk << 2) | (stochastic ? 16u : 0u) | ((uint32_t)s->occupancy << 5);
+        const size_t olds = tile_kernel_lds_bytes(PT, lds_scene);
+        if (s->tile_occ.key != okey || s->tile_occ.lds != olds) {
+            HIP_TRY(tile_kernel_resident_blocks(PT, count, lds_scene, walk, s->occupancy, &s->tile_occ.blocks));
+            s->tile_occ.key = okey; s->tile_occ.lds = olds;
         }
-        if (pk.pending >= 0) {              // collect the measurement of the previous frame
-            HIP_TRY(hipEventSynchronize(s->ev_pick[1]));
-            HIP_TRY(hipEventElapsedTime(&pk.ms[pk.pending], s->ev_pick[0], s->ev_pick[1]));
-            pk.pending = -1;
-        }
-        if (pk.ms[0] < 0.0f) measuring = 0;
-        else if (pk.ms[1] < 0.0f) measuring = 1;
-        tree_requested = measuring >= 0 ? measuring == 1 : pk.ms[1] < pk.ms[0];
+        tile_blocks = s->tile_occ.blocks;
+        tile_blocks = std::min(tile_blocks, PT.n_tiles);
+        tile_blocks = (int)std::min<size_t>((size_t)tile_blocks, s->workspace_budget / slot_bytes);
+        // fewer resident workgroups than a quarter of the CUs: the per-tile worst case of this depth does not fit
+        tile_ok = tile_blocks >= std::min(64, PT.n_tiles);
     }
     // wavefront bands: worst-case queues for a band of tile rows must fit the workspace budget
     const size_t tile_row_px = (size_t)P.tiles_x * 64 * P.wg_waves;
@@ -542,12 +589,66 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     size_t band_tile_rows = wf_bpp ? s->workspace_budget / lanes / (wf_bpp * tile_row_px) : (size_t)P.tiles_y;
     if (wf_bpp == 0) band_tile_rows = (size_t)P.tiles_y;
     band_tile_rows = std::min<size_t>(band_tile_rows, (size_t)P.tiles_y);
-    const bool use_tree = tree_requested || band_tile_rows == 0;
-    if (use_tree && stochastic) return fail(P3D_ERR_LIMIT, "workspace budget too small for the wavefront schedule the features need");
-    s->last_schedule = use_tree ? 1 : 0;
-    size_t lds = use_tree ? tree_kernel_lds_bytes(P, lds_scene) : wavefront_lds_bytes(P, lds_scene);
+    const bool wavefront_ok = band_tile_rows > 0;
+
+    int sched = SCHED_TILE;
+    int measuring = -1;                 // schedule this frame is timed as, for the pick below
+    if (prm->flags & P3D_FLAG_TREE_KERNEL) sched = SCHED_TREE;
+    else if (prm->flags & P3D_FLAG_WAVEFRONT) sched = SCHED_WAVEFRONT;
+    else if (prm->flags & P3D_FLAG_TILE_KERNEL) sched = SCHED_TILE;
+    else {
+        // No schedule wins everywhere (one 1080p frame of a 12-primitive scene: wavefront 0.14 ms, tile 0.22;
+        // 4096^2 x 4 samples of it: tile 5.1, wavefront 5.4; the dragon: tree = tile 2.3, wavefront 3.6; 1e6
+        // random primitives: wavefront 3.7, tile 6.1, tree 9.5), so the library MEASURES: the first frames of a
+        // configuration run every available schedule twice -- the first time untimed: code-object load,
+        // workspace allocation -- and the fastest one stays.  All produce identical bits.
+        const bool avail[3] = {wavefront_ok, !stochastic, tile_ok};
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s->stream, &cap);
+        p3d_scene::SchedulePick& pk = s->pick;
+        const int32_t key[8] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world,
+                                (int32_t)((prm->flags & (P3D_FLAG_NO_LDS_SCENE | P3D_FLAG_NO_PACKET | P3D_FLAG_COUNTERS)) | (prm->features << 8))};
+        if (cap != hipStreamCaptureStatusNone) {
+            // events cannot be read while the stream is being captured: use what is known, measure nothing
+            if (memcmp(key, pk.key, sizeof key) == 0 && pk.step >= 2 * 3) sched = pk.best;
+        } else {
+            if (memcmp(key, pk.key, sizeof key) != 0) {
+                memcpy(pk.key, key, sizeof key);
+                pk.ms[0] = pk.ms[1] = pk.ms[2] = -1.0f; pk.pending = -1; pk.step = 0; pk.best = SCHED_TILE;
+            }
+            if (pk.pending >= 0) {              // collect the measurement of the previous frame
+                HIP_TRY(hipEventSynchronize(s->ev_pick[1]));
+                float ms = 0.0f;
+                HIP_TRY(hipEventElapsedTime(&ms, s->ev_pick[0], s->ev_pick[1]));
+                if (pk.ms[pk.pending] < 0.0f || ms < pk.ms[pk.pending]) pk.ms[pk.pending] = ms;
+                pk.pending = -1;
+            }
+            while (pk.step < 2 * 3 && !avail[pk.step / 2]) pk.step = (pk.step / 2 + 1) * 2;     // skip what cannot run
+            if (pk.step < 2 * 3) {
+                sched = pk.step / 2;
+                if (pk.step & 1) measuring = sched;
+                pk.step++;
+            } else {
+                if (pk.step == 2 * 3) {
+                    pk.best = -1;
+                    for (int k = 0; k < 3; k++)
+                        if (avail[k] && pk.ms[k] >= 0.0f && (pk.best < 0 || pk.ms[k] < pk.ms[pk.best])) pk.best = k;
+                    if (pk.best < 0) pk.best = tile_ok ? SCHED_TILE : (wavefront_ok ? SCHED_WAVEFRONT : SCHED_TREE);
+                    pk.step++;
+                }
+                sched = pk.best;
+            }
+        }
+    }
+    // a schedule whose workspace does not fit falls back: tile -> wavefront (bands) -> tree
+    if (sched == SCHED_TILE && !tile_ok) sched = wavefront_ok ? SCHED_WAVEFRONT : SCHED_TREE;
+    if (sched == SCHED_WAVEFRONT && !wavefront_ok) sched = SCHED_TREE;
+    if (sched == SCHED_TREE && stochastic) return fail(P3D_ERR_LIMIT, "workspace budget too small for the schedules the features need");
+    const bool use_tree = sched == SCHED_TREE, use_tile = sched == SCHED_TILE;
+    s->last_schedule = sched;
+    size_t lds = use_tree ? tree_kernel_lds_bytes(P, lds_scene) : use_tile ? tile_kernel_lds_bytes(PT, lds_scene) : wavefront_lds_bytes(P, lds_scene);
     if (lds > kMaxLdsBytes) return fail(P3D_ERR_LIMIT, "BVH depth / max_depth need more LDS than a CU has");
-    if (lds > 64 * 1024 && !s->lds_prepared) {
+    if (lds > 64 * 1024 && !use_tile && !s->lds_prepared) {
         HIP_TRY(prepare_kernels(kMaxLdsBytes));
         s->lds_prepared = kMaxLdsBytes;
     }
@@ -555,9 +656,13 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     const size_t npx = (size_t)P.local_rows * cam->res_x;
     if (prm->spp > 0) {
         size_t bytes = (size_t)cam->res_y * cam->res_x * prm->spp * prm->spp * 4 * sizeof(float);
-        HIP_TRY(s->samples.ensure(bytes));
-        HIP_TRY(hipMemcpyAsync(s->samples.p, prm->samples, bytes, hipMemcpyHostToDevice, s->stream));
-        P.samples = (const float*)s->samples.p;
+        if (prm->flags & P3D_FLAG_DEVICE_SAMPLES) {
+            P.samples = prm->samples;                      // already on this device (uploaded once by the caller)
+        } else {
+            HIP_TRY(s->samples.ensure(bytes));
+            HIP_TRY(hipMemcpyAsync(s->samples.p, prm->samples, bytes, hipMemcpyHostToDevice, s->stream));
+            P.samples = (const float*)s->samples.p;
+        }
     }
     if (out->memory == 1) {
         P.rgb8 = out->rgb8; P.rgb32f = out->rgb32f; P.hit_id = out->hit_id;
@@ -566,22 +671,36 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         if (out->rgb32f) { HIP_TRY(s->fb_rgb32f.ensure(npx * 12)); P.rgb32f = (float*)s->fb_rgb32f.p; }
         if (out->hit_id) { HIP_TRY(s->fb_hit.ensure(npx * 4)); P.hit_id = (int32_t*)s->fb_hit.p; }
     }
-    bool count = (prm->flags & P3D_FLAG_COUNTERS) != 0;
     if (count) {
-        HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(DeviceCounters), s->stream));
+        HIP_TRY(launch_clear_words((uint32_t*)s->d_counters, (uint32_t)(sizeof(DeviceCounters) / 4), s->stream));
         s->counters_valid = true;
     }
     P.wf_nsamples = prm->spp > 0 ? prm->spp * prm->spp : 1;
     const bool profile = (prm->flags & P3D_FLAG_PROFILE) != 0;
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[0], s->stream));
-    if (use_tree) {
+    if (use_tile) {
+        // (resident workgroups) x (one tile's worst-case queues); the tile counter and the exit ticket are
+        // zeroed once here and re-armed by the kernel itself at the end of every launch
+        HIP_TRY(s->tile_ws.ensure((size_t)tile_blocks * slot_bytes));
+        if (!s->tile_ctrl.p) {
+            HIP_TRY(s->tile_ctrl.ensure(256));
+            HIP_TRY(launch_clear_words((uint32_t*)s->tile_ctrl.p, 64, s->stream));
+        }
+        PT.samples = P.samples; PT.rgb8 = P.rgb8; PT.rgb32f = P.rgb32f; PT.hit_id = P.hit_id;
+        PT.wf_nsamples = P.wf_nsamples;
+        PT.tw_base = (uint8_t*)s->tile_ws.p; PT.tw_slot_bytes = slot_bytes; PT.tw_ctrl = (uint32_t*)s->tile_ctrl.p;
+        PT.tw_rays_off = 0; PT.tw_nodes_off = (uint32_t)slot_rays; PT.tw_rng_off = (uint32_t)(slot_rays + slot_nodes);
+        if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));
+        if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
+        HIP_TRY(launch_wf_tile(PT, count, lds_scene, walk, s->occupancy, (unsigned)tile_blocks, s->stream));
+        if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream));
+    } else if (use_tree) {
         if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));
         P.wf_tile_row0 = 0; P.wf_tile_rows = P.tiles_y;
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
         HIP_TRY(launch_tree(P, count, lds_scene, s->occupancy, s->stream));
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream));
     } else {
-        const int D = prm->max_depth;
         // a shard owns every kShards-th tile of the band
         const size_t band_tiles = band_tile_rows * (size_t)P.tiles_x;
         const size_t shard_px = ((band_tiles + kShards - 1) / kShards) * 64 * P.wg_waves;
@@ -589,8 +708,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
             p3d_scene::Workspace& w = s->ws[ln];
             for (int l = 2; l <= D; l++) HIP_TRY(w.rays[l].ensure((shard_px << (l - 1)) * kShards * sizeof(RayRec)));
             for (int l = 1; l <= D - 1; l++) HIP_TRY(w.nodes[l].ensure((shard_px << (l - 1)) * kShards * sizeof(NodeRec)));
-            if (!w.counts.p) { w.clean[0] = w.clean[1] = false; }
-            HIP_TRY(w.counts.ensure((size_t)2 * 2 * (kMaxDepth + 2) * kShards * sizeof(uint32_t)));
+            HIP_TRY(w.counts.ensure((size_t)2 * (kMaxDepth + 2) * kShards * sizeof(uint32_t)));
             if (stochastic)
                 for (int l = 2; l <= D; l++) HIP_TRY(w.rng[l].ensure((shard_px << (l - 1)) * kShards * sizeof(uint32_t)));
         }
@@ -614,7 +732,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
                 B.n_tiles = B.tiles_x * B.wf_tile_rows;
                 int chunks = (B.n_tiles + B.xcd_chunk - 1) / B.xcd_chunk;
                 B.grid_blocks = ((chunks + 7) / 8) * 8 * B.xcd_chunk;
-                int rc = run_wavefront_pass(s, s->ws[ln], lane_stream, B, count, lds_scene, packet, shard_px,
+                int rc = run_wavefront_pass(s, s->ws[ln], lane_stream, B, count, lds_scene, walk, shard_px,
                                             profile && smp == 0 && r0 == 0);
                 if (rc) return rc;
             }
@@ -629,9 +747,9 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     if (profile) { HIP_TRY(hipEventRecord(s->ev_prof[1], s->stream)); s->profile_valid = true; }
     if (measuring >= 0) {
         HIP_TRY(hipEventRecord(s->ev_pick[1], s->stream));
-        // a frame forced onto the tree schedule by the workspace budget measures the tree schedule
-        s->pick.pending = use_tree ? 1 : 0;
-        if (use_tree && measuring == 0) s->pick.ms[0] = 3.0e38f;
+        // a frame pushed onto another schedule by the workspace budget says the measured one is not available
+        if (sched == measuring) s->pick.pending = sched;
+        else s->pick.ms[measuring] = 3.0e38f;
     }
     if (out->memory != 1) {
         // host planes hold res_y rows for a whole frame, p3d_local_rows() rows for a shard
@@ -738,6 +856,13 @@ int p3d_device_free(p3d_scene* s, void* ptr) {
     if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
     HIP_TRY(hipSetDevice(s->device));
     if (ptr) HIP_TRY(hipFree(ptr));
+    return P3D_OK;
+}
+int p3d_upload(p3d_scene* s, void* device_dst, const void* host_src, uint64_t bytes) {
+    if (!s || !device_dst || !host_src) return fail(P3D_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(device_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
     return P3D_OK;
 }
 int p3d_download(p3d_scene* s, void* host_dst, const void* device_src, uint64_t bytes) {

@@ -44,74 +44,91 @@ __device__ __forceinline__ uint32_t u8fromfloat(float x) {              // RT/ma
 struct Ray { V3 o, d; };
 
 // ------------------------------------------------------------------ primitive tests
+// Written WITHOUT per-lane early returns: every lane evaluates the reference's expressions in the reference's
+// order and carries an `ok` predicate; lanes that the reference would have returned from earlier compute
+// garbage that is never used.  On gfx950 a scalar-unit instruction costs about three vector instructions of
+// issue time (measured: 5.2 vs 1.7 cycles per wave-instruction per SIMD, tools/ubench/valu_rate.hip), and every
+// divergent `if` is three of them (s_and_saveexec / s_cbranch_execz / s_or exec) plus hazard s_nops: the branchy
+// form of these tests made the level-1 kernel scalar-bound (459 SALU per wave).  Each test keeps ONE wave-level
+// exit -- no active lane can still hit -- taken after its cheapest rejection.  Same arithmetic, same bits.
+
 // Triangle::intercepts, RT/scene.cpp:55-88 (e1, e2 are the stored P1-P0, P2-P0)
 __device__ __forceinline__ bool hit_triangle(const Ray& r, V3 p0, V3 e1, V3 e2, float& t) {
-    V3 h = cross(r.d, e2);
-    float det = dot(e1, h);
-    if (det > -P3D_EPS && det < P3D_EPS) return false;
-    float f = fdiv(1.0f, det);
-    V3 s = sub(r.o, p0);
-    float u = f * dot(s, h);
-    if (u < 0.0f || u > 1.0f) return false;
-    V3 q = cross(s, e1);
-    float v = f * dot(r.d, q);
-    if (v < 0.0f || u + v > 1.0f) return false;
-    float t0 = f * dot(e2, q);
-    if (t0 > P3D_EPS) { t = t0; return true; }
-    return false;
+    const V3 h = cross(r.d, e2);
+    const float det = dot(e1, h);
+    bool ok = !(det > -P3D_EPS && det < P3D_EPS);
+    if (__ballot(ok) == 0) return false;
+    const float f = fdiv(1.0f, det);
+    const V3 s = sub(r.o, p0);
+    const float u = f * dot(s, h);
+    ok = ok & !(u < 0.0f || u > 1.0f);
+    const V3 q = cross(s, e1);
+    const float v = f * dot(r.d, q);
+    ok = ok & !(v < 0.0f || u + v > 1.0f);
+    const float t0 = f * dot(e2, q);
+    ok = ok & (t0 > P3D_EPS);
+    t = t0;
+    return ok;
 }
 // Sphere::intercepts, RT/scene.cpp:149-172
 __device__ __forceinline__ bool hit_sphere(const Ray& r, V3 c, float radius, float& t) {
-    V3 L = sub(r.o, c);
-    float a = dot(r.d, r.d);
-    float b = dot(r.d, L) * 2.0f;
-    float cc = dot(L, L) - radius * radius;
-    float delta = b * b - 4.0f * a * cc;
-    if (delta < 0.0f) return false;
-    float sq = fsqrt(delta);
+    const V3 L = sub(r.o, c);
+    const float a = dot(r.d, r.d);
+    const float b = dot(r.d, L) * 2.0f;
+    const float cc = dot(L, L) - radius * radius;
+    const float delta = b * b - 4.0f * a * cc;
+    bool ok = !(delta < 0.0f);
+    if (__ballot(ok) == 0) return false;
+    const float sq = fsqrt(delta);
     float t0 = fdiv(-b - sq, 2.0f * a);
     float t1 = fdiv(-b + sq, 2.0f * a);
-    if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
-    if (t0 < 0.0f) { t0 = t1; if (t0 < 0.0f) return false; }
-    t = t0;
-    return true;
+    const bool sw = t0 > t1;                                   // if (t0 > t1) swap(t0, t1)
+    const float lo = sw ? t1 : t0, hi = sw ? t0 : t1;
+    const bool neg = lo < 0.0f;                                // if (t0 < 0) { t0 = t1; if (t0 < 0) return false; }
+    t = neg ? hi : lo;
+    ok = ok & !(neg && hi < 0.0f);
+    return ok;
 }
 // aaBox::intercepts, RT/scene.cpp:198-278; nrm = the face normal the reference stores as a
 // side effect
 __device__ __forceinline__ bool hit_aabox(const Ray& r, V3 mn, V3 mx, float& t, V3& nrm) {
-    float tminx, tminy, tminz, tmaxx, tmaxy, tmaxz;
     float aux = fdiv(1.0f, r.d.x);
-    if (aux >= 0.0f) { tminx = (mn.x - r.o.x) * aux; tmaxx = (mx.x - r.o.x) * aux; }
-    else             { tminx = (mx.x - r.o.x) * aux; tmaxx = (mn.x - r.o.x) * aux; }
+    const float ax0 = (mn.x - r.o.x) * aux, ax1 = (mx.x - r.o.x) * aux;
+    const float tminx = aux >= 0.0f ? ax0 : ax1, tmaxx = aux >= 0.0f ? ax1 : ax0;
     aux = fdiv(1.0f, r.d.y);
-    if (aux >= 0.0f) { tminy = (mn.y - r.o.y) * aux; tmaxy = (mx.y - r.o.y) * aux; }
-    else             { tminy = (mx.y - r.o.y) * aux; tmaxy = (mn.y - r.o.y) * aux; }
+    const float ay0 = (mn.y - r.o.y) * aux, ay1 = (mx.y - r.o.y) * aux;
+    const float tminy = aux >= 0.0f ? ay0 : ay1, tmaxy = aux >= 0.0f ? ay1 : ay0;
     aux = fdiv(1.0f, r.d.z);
-    if (aux >= 0.0f) { tminz = (mn.z - r.o.z) * aux; tmaxz = (mx.z - r.o.z) * aux; }
-    else             { tminz = (mx.z - r.o.z) * aux; tmaxz = (mn.z - r.o.z) * aux; }
-    float tIn, tOut; V3 fIn, fOut;
-    if (tminx > tminy) { tIn = tminx; fIn = mk(tminx < 0.0f ? -1.0f : 1.0f, 0.0f, 0.0f); }
-    else               { tIn = tminy; fIn = mk(0.0f, tminy < 0.0f ? -1.0f : 1.0f, 0.0f); }
-    if (tminz > tIn)   { tIn = tminz; fIn = mk(0.0f, 0.0f, tminz < 0.0f ? -1.0f : 1.0f); }
-    if (tmaxx < tmaxy) { tOut = tmaxx; fOut = mk(tmaxx < 0.0f ? -1.0f : 1.0f, 0.0f, 0.0f); }
-    else               { tOut = tmaxy; fOut = mk(0.0f, tmaxy < 0.0f ? -1.0f : 1.0f, 0.0f); }
-    if (tmaxz < tOut)  { tOut = tmaxz; fOut = mk(0.0f, 0.0f, tmaxz < 0.0f ? -1.0f : 1.0f); }
-    if (tIn < tOut && tOut > P3D_EPS) {
-        if (tIn > P3D_EPS) { t = tIn; nrm = fIn; }
-        else               { t = tOut; nrm = fOut; }
-        return true;
-    }
-    return false;
+    const float az0 = (mn.z - r.o.z) * aux, az1 = (mx.z - r.o.z) * aux;
+    const float tminz = aux >= 0.0f ? az0 : az1, tmaxz = aux >= 0.0f ? az1 : az0;
+    // entering face: x if tminx > tminy else y; then z if tminz > that
+    const bool inx = tminx > tminy;
+    float tIn = inx ? tminx : tminy;
+    const bool inz = tminz > tIn;
+    const float sIn = (inz ? tminz : tIn) < 0.0f ? -1.0f : 1.0f;         // sign rule of the chosen axis' tmin
+    tIn = inz ? tminz : tIn;
+    const V3 fIn = mk(inz ? 0.0f : (inx ? sIn : 0.0f), inz ? 0.0f : (inx ? 0.0f : sIn), inz ? sIn : 0.0f);
+    const bool outx = tmaxx < tmaxy;
+    float tOut = outx ? tmaxx : tmaxy;
+    const bool outz = tmaxz < tOut;
+    const float sOut = (outz ? tmaxz : tOut) < 0.0f ? -1.0f : 1.0f;
+    tOut = outz ? tmaxz : tOut;
+    const V3 fOut = mk(outz ? 0.0f : (outx ? sOut : 0.0f), outz ? 0.0f : (outx ? 0.0f : sOut), outz ? sOut : 0.0f);
+    const bool ok = tIn < tOut && tOut > P3D_EPS;
+    const bool entering = tIn > P3D_EPS;
+    t = entering ? tIn : tOut;
+    nrm = entering ? fIn : fOut;
+    return ok;
 }
 // Plane::intercepts, RT/scene.cpp:122-141
 __device__ __forceinline__ bool hit_plane(const Ray& r, V3 pn, float D, float& t) {
-    float denominator = dot(pn, r.d);
-    if (fabsf(denominator) < P3D_EPS) return false;
-    float numerator = dot(pn, r.o) + D;
-    float taux = -fdiv(numerator, denominator);
-    if (taux <= 0.0f) return false;
+    const float denominator = dot(pn, r.d);
+    bool ok = !(fabsf(denominator) < P3D_EPS);
+    const float numerator = dot(pn, r.o) + D;
+    const float taux = -fdiv(numerator, denominator);
+    ok = ok & !(taux <= 0.0f);
     t = taux;
-    return true;
+    return ok;
 }
 // AABB::intercepts, RT/boundingBox.cpp:64-124, only for the default [-1,1]^3 box that
 // bounds planes inside the reference's BVH / grid

@@ -5,6 +5,12 @@
 
 #include <stdint.h>
 
+#if defined(__HIPCC__)
+#define P3D_HD __host__ __device__
+#else
+#define P3D_HD
+#endif
+
 namespace p3d {
 
 // One BVH2 inner node = both children's boxes + both child references: 64 B, four
@@ -96,7 +102,7 @@ struct LaunchParams {
     uint32_t wf_cap_in, wf_cap_out, wf_ncap_parent, wf_ncap_self;    // entries per shard
     const RayRec* wf_rays_in;  const uint32_t* wf_count_in;      // level wf_level queue
     RayRec* wf_rays_out;       uint32_t* wf_count_out;           // level wf_level + 1 queue
-    uint32_t* wf_clear; uint32_t wf_clear_words;                  // counters of the next pass, zeroed by the level-1 launch
+    uint32_t* wf_clear; uint32_t wf_clear_words;                  // (unused)
     NodeRec* wf_nodes_parent;                                     // level wf_level - 1 nodes
     NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
     float* wf_planes; uint64_t wf_plane_stride;                   // [sample][local px][3] clamped sample colours; floats per plane
@@ -106,7 +112,28 @@ struct LaunchParams {
     uint32_t features, seed;
     const uint32_t* wf_rng_in; uint32_t* wf_rng_out;
     unsigned long long* dbg_stamps;   // diagnostic: per (tile, wave) 8 x u64 timestamps, or nullptr
+    // ---- uniform grid of GRID mode (accel 1; RT/grid.cpp): cell c holds grid_items[grid_cells[c] .. grid_cells[c+1])
+    // = primitive refs (kind << 30 | index, planes kind 3) in scene order; nullptr until a GRID frame is asked for
+    const uint32_t* grid_cells; const uint32_t* grid_items;
+    int32_t grid_n[3]; float grid_min[3], grid_max[3];
+    // ---- tile schedule (wf_tile_kernel): ONE launch per frame.  Persistent 256-thread workgroups draw
+    // 16x16-pixel tiles from tw_ctrl[0] and run a tile's whole ray tree level by level among themselves;
+    // every queue of a tile lives in the workgroup's private slot of the workspace (slot = blockIdx.x),
+    // its counters in LDS.  tw_ctrl[1] counts workgroups that have finished: the last one resets both.
+    uint8_t*  tw_base; uint64_t tw_slot_bytes;
+    uint32_t* tw_ctrl;
+    uint32_t  tw_rays_off, tw_nodes_off, tw_rng_off;     // byte offsets of the three regions inside a slot
 };
+
+// tile schedule geometry: a tile is 16 x 16 pixels = one 256-thread workgroup = 4 waves of 16 x 4
+constexpr uint32_t kTilePx = 256;
+constexpr int kMaxTileLevels = 18;        // max_depth <= 16: levels 0..17 index the per-tile counters
+// level l (1-based) of a tile's tree holds at most kTilePx << (l-1) rays / nodes; levels are packed back to back:
+// ray queues start at level 2, node arrays at level 1
+P3D_HD inline uint32_t tile_ray_offset(int l) { return kTilePx * ((1u << (l - 1)) - 2u); }
+P3D_HD inline uint32_t tile_node_offset(int l) { return kTilePx * ((1u << (l - 1)) - 1u); }
+P3D_HD inline uint64_t tile_ray_entries(int D) { return D >= 2 ? (uint64_t)kTilePx * ((1ull << D) - 2ull) : 0; }
+P3D_HD inline uint64_t tile_node_entries(int D) { return D >= 2 ? (uint64_t)kTilePx * ((1ull << (D - 1)) - 1ull) : 0; }
 
 }  // namespace p3d
 #endif

@@ -239,14 +239,17 @@ __device__ __forceinline__ void stamp(const LaunchParams& P, int tile, int k) {
 // OCC = requested waves per SIMD (amdgpu_waves_per_eu): caps the VGPR allocation so that more
 // waves hide each other's latency, at the price of a few spilled registers.  Selected at run
 // time by p3d_set_tuning(); never changes results.
-#define P3D_OCC(OCC) __attribute__((amdgpu_waves_per_eu(OCC, 8)))
+#ifndef P3D_OCC_FLOOR
+#define P3D_OCC_FLOOR 1          // build-time experiment knob: minimum waves per SIMD of every ray kernel
+#endif
+#define P3D_OCC(OCC) __attribute__((amdgpu_waves_per_eu(((OCC) > P3D_OCC_FLOOR ? (OCC) : P3D_OCC_FLOOR), 8)))
 
-template <bool COUNT, bool LDS, bool PACKET, int OCC, bool STOCH = false>
+// One workgroup per 16 x (4 x wg_waves) tile, dispatched by the hardware.  (A persistent variant -- resident-sized
+// grid, scene copied once per workgroup, every wave drawing 16x4 tiles from device counters with the next number
+// prefetched -- was measured and dropped: 520 us with one counter (a word saturates at ~88 returning atomics per
+// microsecond), 110 us with 64 counters on separate lines, against 50 us for this plain grid.)
+template <bool COUNT, bool LDS, int WALK, int OCC, bool STOCH = false>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel(const LaunchParams P) {
-    // the queue counters of the NEXT pass over this workspace (the other half of a double buffer nothing
-    // touches during this pass): cleared here instead of by a memset launch in front of every frame
-    if (blockIdx.x == 0)
-        for (uint32_t i = threadIdx.x; i < P.wf_clear_words; i += blockDim.x) P.wf_clear[i] = 0u;
     const typename View<LDS>::type sv = View<LDS>::make(P);
     int x, y, row, tile;
     const bool valid = tile_pixel(P, x, y, row, &tile);
@@ -259,13 +262,13 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel
     Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
     if (valid) ray = camera_ray(P, x, y, P.wf_sample);
     stamp(P, tile, 1);
-    const Hit h = find_closest<COUNT, PACKET>(P, sv, ray, valid, tc, ctr);
+    const Hit h = find_closest<COUNT, WALK>(P, sv, ray, valid, tc, ctr);
     stamp(P, tile, 2);
     if (valid && P.hit_id && P.wf_sample == 0) P.hit_id[p] = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid;
     // the random stream of a pixel sample is keyed by the pixel's place in the FULL frame, so a frame
     // sharded over several GPUs draws the same numbers as on one
     const uint32_t rng = STOCH ? rng_mix(rng_mix(P.seed, (uint32_t)(y * P.res_x + x)), (uint32_t)P.wf_sample) : 0u;
-    const NodeOut o = shade_hit<COUNT, PACKET, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr, rng);
+    const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr, rng);
     stamp(P, tile, 3);
     emit(P, sh, 1, valid, (uint32_t)p, 1.0f, o);
     stamp(P, tile, 4);
@@ -288,11 +291,52 @@ __device__ __forceinline__ uint32_t wave_width(uint32_t count, uint32_t waves_pe
 }
 
 // level >= 2: one queued ray per lane, persistent waves striding over the queue
-template <bool COUNT, bool LDS, bool PACKET, int OCC, bool STOCH = false>
+template <bool COUNT, bool LDS, int WALK, int OCC, bool STOCH = false>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kernel(const LaunchParams P) {
-    // wave g works on shard g % S; the (gridwaves / S) waves of a shard stride over its queue
     const uint32_t S = (uint32_t)P.wf_shards;
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (LDS) {
+        // Scenes served from LDS: full 64-ray batches, numbered THROUGH all shards (the host launches S == 64
+        // shards, one count per lane: batches per shard, wave-wide prefix sum), batch b goes to wave b % n_waves.
+        // A deeper level of a 1080p frame is ~1.15 batches per resident-at-4-per-SIMD wave, and a launch lasts as
+        // long as its busiest wave: with the grid sized to what can be RESIDENT (host: occupancy query) and every
+        // wave owning at most one batch whichever shard it is in, the level costs one ray step instead of two.
+        const uint32_t c = (uint32_t)lane < S ? P.wf_count_in[lane] : 0u;
+        const uint32_t nb = (c + 63u) >> 6;
+        uint32_t incl = nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        const uint32_t total = __shfl(incl, 63);
+        if (((blockIdx.x * blockDim.x) >> 6) >= total) return;      // workgroup-uniform, before the scene copy's barrier
+        const typename View<LDS>::type sv = View<LDS>::make(P);
+        const TravCtx tc = wave_stack<LDS>(P, 0);
+        Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t b = wave_id; b < total; b += n_waves) {
+            const int s = (int)__builtin_ctzll(__ballot(incl > b));  // the shard batch b belongs to
+            const uint32_t first = __shfl(incl - nb, s);             // batches in the shards before it
+            const Shard sh = shard_of(P, (uint32_t)s);
+            const uint32_t i = (b - first) * 64u + lane;
+            const bool valid = i < sh.count_in;
+            uint32_t link = 0, rng = 0; float ior_1 = 1.0f;
+            Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
+            if (valid) {
+                const float4* rq = reinterpret_cast<const float4*>(sh.rays_in + i);
+                float4 a = rq[0], bq = rq[1];
+                ray.o = mk(a.x, a.y, a.z); ray.d = mk(bq.x, bq.y, bq.z);
+                ior_1 = a.w; link = __float_as_uint(bq.w);
+                if (STOCH) rng = sh.rng_in[i];
+            }
+            const Hit h = find_closest<COUNT, WALK>(P, sv, ray, valid, tc, ctr);
+            const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, P.wf_level, ior_1, tc,
+                                                                                    ctr, rng);
+            emit(P, sh, P.wf_level, valid, link, ior_1, o);
+        }
+        flush_counters<COUNT>(P, ctr, 0u);
+        return;
+    }
+    // Scenes read from HBM: wave g works on shard g % S; the (gridwaves / S) waves of a shard stride over its
+    // queue, with narrow waves when the queue is short (wave_width)
     const uint32_t per_shard = n_waves / S;
     {   // workgroup-uniform early exit (before the scene copy's barrier): nothing queued for any of
         // this workgroup's waves
@@ -306,7 +350,6 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
     }
     const typename View<LDS>::type sv = View<LDS>::make(P);
     const Shard sh = shard_of(P, wave_id % S);
-    const int lane = threadIdx.x & 63;
     const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
     const uint32_t width = wave_width(sh.count_in, per_shard, (uint32_t)P.wf_min_width);
@@ -322,9 +365,9 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
             ior_1 = a.w; link = __float_as_uint(b.w);
             if (STOCH) rng = sh.rng_in[i];
         }
-        const Hit h = find_closest<COUNT, PACKET>(P, sv, ray, valid, tc, ctr);
-        const NodeOut o = shade_hit<COUNT, PACKET, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, P.wf_level, ior_1, tc,
-                                                                                  ctr, rng);
+        const Hit h = find_closest<COUNT, WALK>(P, sv, ray, valid, tc, ctr);
+        const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, P.wf_level, ior_1, tc,
+                                                                                ctr, rng);
         emit(P, sh, P.wf_level, valid, link, ior_1, o);
     }
     flush_counters<COUNT>(P, ctr, 0u);
@@ -343,6 +386,188 @@ __global__ __launch_bounds__(256) void wf_resolve_kernel(const LaunchParams P) {
         Mtl M = load_material(gv, __float_as_uint(b.w));
         V3 ret = combine_node(mk(a.x, a.y, a.z), a.w, M.spec, mk(b.x, b.y, b.z), mk(c.x, c.y, c.z));
         deliver(P, sh, P.wf_level, __float_as_uint(c.w), ret);
+    }
+}
+
+// ------------------------------------------------------------------ TILE schedule
+// ONE launch per frame.  The wavefront schedule above spends six of its seven launches on the deeper
+// levels of a 1080p frame, each lasting as long as one or two incoherent ray steps of a wave whatever
+// the number of rays (launch ramp + quantisation: 1.15 batches per wave rounds up to 2), and hands rays
+// from level to level through device-scope atomics and HBM-sized worst-case queues.  A ray never leaves
+// its pixel's tile, so here a 256-thread workgroup keeps a 16x16 tile's whole tree to itself: level 1
+// traces the camera rays, child rays are compacted (ballot + mbcnt, one LDS atomic per counter per wave)
+// into the workgroup's PRIVATE slot of the workspace, the four waves share each deeper level's batches,
+// and the resolve passes walk the levels back up -- all between __syncthreads(), no global atomics, no
+// cross-CU hand-off (a workgroup's own stores are visible to it after the barrier).  Workgroups are
+// persistent and draw tiles from one counter, so cheap sky tiles flow past expensive glass tiles and the
+// workspace is (resident workgroups) x (one tile's worst case): ~200 MB at depth 4 instead of gigabytes.
+// Samples of the anti-aliased path run back to back inside the tile: "color += rayTracing().clamp()" in
+// sample order is an LDS accumulator, there are no per-sample planes and no summing launch.
+// Same shade_hit()/combine_node() as the other schedules: bit-identical frames.
+struct TileLds {
+    uint32_t n_rays[kMaxTileLevels];      // rays queued for level l (2..D)
+    uint32_t n_nodes[kMaxTileLevels];     // nodes parked at level l (1..D-1)
+    uint32_t tile, pad;
+    float acc[3 * kTilePx];               // sum of the clamped sample colours of each pixel (spp > 0)
+};
+
+struct TileCtx {
+    uint32_t lds_off;                     // dword offset of the TileLds inside p3d_lds
+    RayRec* rays; NodeRec* nodes; uint32_t* keys;     // this workgroup's slot
+    int tx, ty;                           // tile coordinates
+    __device__ __forceinline__ TileLds* lds() const { return reinterpret_cast<TileLds*>(p3d_lds + lds_off); }
+};
+
+// compact pixel index of tile-local pixel `link` (= the thread id that traced it)
+__device__ __forceinline__ size_t tile_pixel_index(const LaunchParams& P, const TileCtx& X, uint32_t link) {
+    const int x = X.tx * 16 + (int)(link & 15u);
+    const int row = X.ty * 16 + (int)(link >> 6) * 4 + (int)((link >> 4) & 3u);
+    return (size_t)row * P.res_x + x;
+}
+
+__device__ __forceinline__ void tile_deliver(const LaunchParams& P, const TileCtx& X, int level, uint32_t link, V3 ret) {
+    if (level == 1) {                                            // "rayTracing(...).clamp()" of a pixel sample
+        const V3 c = clampc(ret);
+        if (P.spp == 0) { write_pixel(P, tile_pixel_index(P, X, link), c); return; }
+        float* a = X.lds()->acc + 3 * link;                      // color += ... in sample order (RT/main.cpp:797)
+        a[0] = a[0] + c.x; a[1] = a[1] + c.y; a[2] = a[2] + c.z;
+        return;
+    }
+    NodeRec* parent = X.nodes + tile_node_offset(level - 1) + (link & ~kLinkRefr);
+    float* dst = (link & kLinkRefr) ? parent->refr_ret : parent->refl_ret;
+    dst[0] = ret.x; dst[1] = ret.y; dst[2] = ret.z;
+}
+
+// like emit(): must be reached by all lanes of the wave together
+__device__ __forceinline__ void tile_emit(const LaunchParams& P, const TileCtx& X, int level, bool valid, uint32_t link,
+                                          float ior_1, const NodeOut& o) {
+    const int lane = threadIdx.x & 63;
+    if (valid && o.terminal) tile_deliver(P, X, level, link, o.ret);
+    const bool parks = valid && !o.terminal;
+    const uint64_t m_node = __ballot(parks);
+    if (m_node == 0) return;                                   // wave-uniform
+    const uint64_t m_refl = __ballot(parks && o.has_refl);
+    const uint64_t m_refr = __ballot(parks && o.has_refr);
+    const uint32_t n_refl = (uint32_t)__popcll(m_refl), n_refr = (uint32_t)__popcll(m_refr);
+    uint32_t node_base = 0, ray_base = 0;
+    const int first = (int)__builtin_ctzll(m_node);
+    if (lane == first) {
+        TileLds* T = X.lds();
+        node_base = atomicAdd(&T->n_nodes[level], (uint32_t)__popcll(m_node));
+        ray_base = atomicAdd(&T->n_rays[level + 1], n_refl + n_refr);
+    }
+    node_base = __shfl(node_base, first);
+    ray_base = __shfl(ray_base, first);
+    if (!parks) return;
+    const uint32_t my_node = node_base + lane_rank(m_node);
+    float4* nd = reinterpret_cast<float4*>(X.nodes + tile_node_offset(level) + my_node);
+    nd[0] = make_float4(o.color.x, o.color.y, o.color.z, o.KR);
+    nd[1] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(o.mat));
+    nd[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(link));
+    RayRec* out = X.rays + tile_ray_offset(level + 1);
+    if (o.has_refl) {                                           // reflection child keeps ior_1
+        const uint32_t slot = ray_base + lane_rank(m_refl);
+        float4* rq = reinterpret_cast<float4*>(out + slot);
+        rq[0] = make_float4(o.refl.o.x, o.refl.o.y, o.refl.o.z, ior_1);
+        rq[1] = make_float4(o.refl.d.x, o.refl.d.y, o.refl.d.z, __uint_as_float(my_node));
+        if (X.keys) X.keys[tile_ray_offset(level + 1) + slot] = o.rng_refl;
+    }
+    if (o.has_refr) {
+        const uint32_t slot = ray_base + n_refl + lane_rank(m_refr);
+        float4* rq = reinterpret_cast<float4*>(out + slot);
+        rq[0] = make_float4(o.refr.o.x, o.refr.o.y, o.refr.o.z, o.newIor);
+        rq[1] = make_float4(o.refr.d.x, o.refr.d.y, o.refr.d.z, __uint_as_float(my_node | kLinkRefr));
+        if (X.keys) X.keys[tile_ray_offset(level + 1) + slot] = o.rng_refr;
+    }
+}
+
+template <bool COUNT, bool LDS, int WALK, int OCC, bool STOCH = false>
+__global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchParams P) {
+    const typename View<LDS>::type sv = View<LDS>::make(P);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const TravCtx tc = wave_stack<LDS>(P, 0);
+    TileCtx X;
+    X.lds_off = View<LDS>::scene_dwords(P) + 4u * P.trav_stack_dwords;
+    uint8_t* slot = P.tw_base + (size_t)blockIdx.x * P.tw_slot_bytes;
+    X.rays = reinterpret_cast<RayRec*>(slot + P.tw_rays_off);
+    X.nodes = reinterpret_cast<NodeRec*>(slot + P.tw_nodes_off);
+    X.keys = STOCH ? reinterpret_cast<uint32_t*>(slot + P.tw_rng_off) : nullptr;
+    TileLds* T = X.lds();
+    Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
+    const int D = P.max_depth, ns = P.spp > 0 ? P.spp * P.spp : 1;
+    uint32_t my_pixels = 0;
+    for (;;) {
+        if (tid == 0) T->tile = atomicAdd(&P.tw_ctrl[0], 1u);
+        __syncthreads();
+        const int tile = (int)T->tile;
+        if (tile >= P.n_tiles) break;                            // workgroup-uniform
+        X.tx = tile % P.tiles_x; X.ty = tile / P.tiles_x;
+        const int x = X.tx * 16 + (lane & 15);
+        const int row = X.ty * 16 + wave * 4 + (lane >> 4);      // row in the compact local buffer
+        const int blk = row / P.row_block;
+        const int y = (blk * P.world + P.rank) * P.row_block + (row - blk * P.row_block);
+        const bool inside = x < P.res_x && y < P.res_y;
+        const size_t p = (size_t)row * P.res_x + x;
+        if (P.spp > 0) { T->acc[3 * tid] = 0.0f; T->acc[3 * tid + 1] = 0.0f; T->acc[3 * tid + 2] = 0.0f; }
+        for (int smp = 0; smp < ns; smp++) {
+            if (tid < 2 * kMaxTileLevels) T->n_rays[tid] = 0u;   // n_rays and n_nodes are contiguous
+            __syncthreads();
+            // ---- trace: level 1 = this sample's camera rays (one per thread), level l >= 2 = the queue the
+            // level above filled, shared by the four waves.  ONE call site for both, so that the per-node code
+            // is instantiated once per kernel.
+            for (int l = 1; l <= D; l++) {
+                const uint32_t n = l == 1 ? kTilePx : T->n_rays[l];
+                const RayRec* in = X.rays + tile_ray_offset(l < 2 ? 2 : l);
+                for (uint32_t base = (uint32_t)wave * 64u; base < n; base += 256u) {
+                    const uint32_t i = base + lane;
+                    bool valid; uint32_t link = (uint32_t)tid, rng = 0; float ior_1 = 1.0f;
+                    Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
+                    if (l == 1) {
+                        valid = inside;
+                        if (inside) ray = camera_ray(P, x, y, smp);
+                        if (STOCH) rng = rng_mix(rng_mix(P.seed, (uint32_t)(y * P.res_x + x)), (uint32_t)smp);
+                    } else {
+                        valid = i < n;
+                        if (valid) {
+                            const float4* rq = reinterpret_cast<const float4*>(in + i);
+                            const float4 a = rq[0], b = rq[1];
+                            ray.o = mk(a.x, a.y, a.z); ray.d = mk(b.x, b.y, b.z);
+                            ior_1 = a.w; link = __float_as_uint(b.w);
+                            if (STOCH) rng = X.keys[tile_ray_offset(l) + i];
+                        }
+                    }
+                    const Hit h = find_closest<COUNT, WALK>(P, sv, ray, valid, tc, ctr);
+                    if (l == 1 && smp == 0 && inside && P.hit_id) P.hit_id[p] = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid;
+                    const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, l, ior_1, tc,
+                                                                                              ctr, rng, smp);
+                    tile_emit(P, X, l, valid, link, ior_1, o);
+                }
+                __syncthreads();
+            }
+            for (int l = D - 1; l >= 1; l--) {                   // ---- resolve: RT/main.cpp:719, deepest level first
+                const uint32_t n = T->n_nodes[l];
+                for (uint32_t i = (uint32_t)tid; i < n; i += 256u) {
+                    const float4* nd = reinterpret_cast<const float4*>(X.nodes + tile_node_offset(l) + i);
+                    const float4 a = nd[0], b = nd[1], c = nd[2];
+                    const Mtl M = load_material(sv, __float_as_uint(b.w));
+                    const V3 ret = combine_node(mk(a.x, a.y, a.z), a.w, M.spec, mk(b.x, b.y, b.z), mk(c.x, c.y, c.z));
+                    tile_deliver(P, X, l, __float_as_uint(c.w), ret);
+                }
+                __syncthreads();
+            }
+        }
+        if (P.spp > 0 && inside) {                               // "color / (4 * 4)", RT/main.cpp:800
+            const float* a = T->acc + 3 * tid;
+            write_pixel(P, p, mk(fdiv(a[0], 16.0f), fdiv(a[1], 16.0f), fdiv(a[2], 16.0f)));
+        }
+        my_pixels += inside ? 1u : 0u;
+    }
+    flush_counters<COUNT>(P, ctr, my_pixels);
+    // the last workgroup out re-arms the tile counter for the next launch on this workspace (the frame
+    // is self-contained on the device: safe to capture into a HIP graph and replay)
+    if (tid == 0 && atomicAdd(&P.tw_ctrl[1], 1u) == gridDim.x - 1u) {
+        atomicExch(&P.tw_ctrl[0], 0u);
+        atomicExch(&P.tw_ctrl[1], 0u);
     }
 }
 
@@ -367,7 +592,7 @@ enum { FR_C = 0, FR_KR = 3, FR_META = 4, FR_A = 5, FR_RD = 8, FR_IOR = 11 };
 #define FR_WAIT_REFR 0x80000000u
 
 // One primary ray's whole tree: rayTracing(ray, 1, 1.0) of RT/main.cpp:530-721, iterative.
-template <bool COUNT, class SV>
+template <bool COUNT, bool GRID, class SV>
 __device__ __forceinline__ V3 trace_tree(const LaunchParams& P, const SV& sv, Ray ray, const TravCtx& tc, Frames fr,
                                          int32_t& primary_hit, Ctr& ctr) {
     int fsp = 0;              // frames on the stack == depth - 1
@@ -376,9 +601,9 @@ __device__ __forceinline__ V3 trace_tree(const LaunchParams& P, const SV& sv, Ra
     V3 ret = mk(0.0f, 0.0f, 0.0f);
     const V3 zero = mk(0.0f, 0.0f, 0.0f);
     for (;;) {
-        Hit h = closest_hit<COUNT>(P, sv, ray, tc.lane, ctr);
+        Hit h = find_closest<COUNT, GRID ? WALK_GRID : WALK_LANE>(P, sv, ray, true, tc, ctr);
         if (first) { primary_hit = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid; first = false; }
-        NodeOut o = shade_hit<COUNT, false>(P, sv, ray, h, true, fsp + 1, ior_1, tc, ctr);
+        NodeOut o = shade_hit<COUNT, GRID ? WALK_GRID : WALK_LANE>(P, sv, ray, h, true, fsp + 1, ior_1, tc, ctr);
         if (!o.terminal) {
             fr.put3(fsp, FR_C, o.color);
             fr.f(fsp, FR_KR) = __float_as_uint(o.KR);
@@ -428,7 +653,7 @@ __device__ __forceinline__ V3 trace_tree(const LaunchParams& P, const SV& sv, Ra
     }
 }
 
-template <bool COUNT, bool LDS, int OCC>
+template <bool COUNT, bool LDS, int OCC, bool GRID = false>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kernel(const LaunchParams P) {
     const typename View<LDS>::type sv = View<LDS>::make(P);
     const int lane = threadIdx.x & 63;
@@ -443,12 +668,12 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kern
     V3 color = mk(0.0f, 0.0f, 0.0f);
     int32_t hid = -1;
     if (P.spp == 0) {                                    // RT/main.cpp:756-775
-        color = clampc(trace_tree<COUNT>(P, sv, camera_ray(P, x, y, 0), st, fr, hid, ctr));
+        color = clampc(trace_tree<COUNT, GRID>(P, sv, camera_ray(P, x, y, 0), st, fr, hid, ctr));
     } else {                                             // RT/main.cpp:776-801
         const int ns = P.spp * P.spp;
         for (int s = 0; s < ns; s++) {
             int32_t h2 = -1;
-            V3 c = clampc(trace_tree<COUNT>(P, sv, camera_ray(P, x, y, s), st, fr, h2, ctr));
+            V3 c = clampc(trace_tree<COUNT, GRID>(P, sv, camera_ray(P, x, y, s), st, fr, h2, ctr));
             color = add(color, c);
             if (s == 0) hid = h2;
         }
@@ -545,75 +770,107 @@ size_t wavefront_lds_bytes(const LaunchParams& P, bool lds) {
     return scene_lds_bytes(P, lds) + (size_t)P.trav_stack_dwords * 4 * P.wg_waves;
 }
 
-// counting builds always use the default register budget; timed builds pick OCC
-#define P3D_LAUNCH_OCC(KERNEL, occ, grid, block, shmem, stream, P, ...)                               \
-    do {                                                                                             \
-        switch (occ) {                                                                               \
-        case 5: hipLaunchKernelGGL((KERNEL<false, __VA_ARGS__, 5>), grid, block, shmem, stream, P); break;  \
-        case 6: hipLaunchKernelGGL((KERNEL<false, __VA_ARGS__, 6>), grid, block, shmem, stream, P); break;  \
-        default: hipLaunchKernelGGL((KERNEL<false, __VA_ARGS__, 1>), grid, block, shmem, stream, P); break; \
-        }                                                                                            \
-    } while (0)
+// Kernel variants are picked through function pointers: {count} x {scene in LDS} x {walk: lane / packet / grid}
+// x {register budget: only for the timed non-grid builds} x {random draws}.  Counting, grid and stochastic
+// builds always use the default register budget.
+template <class F> static const void* fn_ptr(F f) { return reinterpret_cast<const void*>(f); }
+#define P3D_DEFINE_SELECTOR(NAME, KERNEL)                                                                         \
+    static const void* NAME(bool count, bool lds, int walk, int occ, bool stoch) {                                \
+        if (walk == WALK_GRID || count || stoch) occ = 1;                                                         \
+        if (stoch) {                                                                                              \
+            if (count) return lds ? (walk == 2 ? fn_ptr(KERNEL<true, true, 2, 1, true>) : walk == 1 ? fn_ptr(KERNEL<true, true, 1, 1, true>) : fn_ptr(KERNEL<true, true, 0, 1, true>))       \
+                                  : (walk == 2 ? fn_ptr(KERNEL<true, false, 2, 1, true>) : walk == 1 ? fn_ptr(KERNEL<true, false, 1, 1, true>) : fn_ptr(KERNEL<true, false, 0, 1, true>));   \
+            return lds ? (walk == 2 ? fn_ptr(KERNEL<false, true, 2, 1, true>) : walk == 1 ? fn_ptr(KERNEL<false, true, 1, 1, true>) : fn_ptr(KERNEL<false, true, 0, 1, true>))              \
+                       : (walk == 2 ? fn_ptr(KERNEL<false, false, 2, 1, true>) : walk == 1 ? fn_ptr(KERNEL<false, false, 1, 1, true>) : fn_ptr(KERNEL<false, false, 0, 1, true>));          \
+        }                                                                                                         \
+        if (count) return lds ? (walk == 2 ? fn_ptr(KERNEL<true, true, 2, 1, false>) : walk == 1 ? fn_ptr(KERNEL<true, true, 1, 1, false>) : fn_ptr(KERNEL<true, true, 0, 1, false>))      \
+                              : (walk == 2 ? fn_ptr(KERNEL<true, false, 2, 1, false>) : walk == 1 ? fn_ptr(KERNEL<true, false, 1, 1, false>) : fn_ptr(KERNEL<true, false, 0, 1, false>));  \
+        if (walk == 2) return lds ? fn_ptr(KERNEL<false, true, 2, 1, false>) : fn_ptr(KERNEL<false, false, 2, 1, false>);                                                                  \
+        if (occ == 5) return lds ? (walk == 1 ? fn_ptr(KERNEL<false, true, 1, 5, false>) : fn_ptr(KERNEL<false, true, 0, 5, false>))                                                        \
+                                 : (walk == 1 ? fn_ptr(KERNEL<false, false, 1, 5, false>) : fn_ptr(KERNEL<false, false, 0, 5, false>));                                                     \
+        if (occ == 6) return lds ? (walk == 1 ? fn_ptr(KERNEL<false, true, 1, 6, false>) : fn_ptr(KERNEL<false, true, 0, 6, false>))                                                        \
+                                 : (walk == 1 ? fn_ptr(KERNEL<false, false, 1, 6, false>) : fn_ptr(KERNEL<false, false, 0, 6, false>));                                                     \
+        return lds ? (walk == 1 ? fn_ptr(KERNEL<false, true, 1, 1, false>) : fn_ptr(KERNEL<false, true, 0, 1, false>))                                                                      \
+                   : (walk == 1 ? fn_ptr(KERNEL<false, false, 1, 1, false>) : fn_ptr(KERNEL<false, false, 0, 1, false>));                                                                   \
+    }
+P3D_DEFINE_SELECTOR(wf_primary_fn, wf_primary_kernel)
+P3D_DEFINE_SELECTOR(wf_secondary_fn, wf_secondary_kernel)
+P3D_DEFINE_SELECTOR(wf_tile_fn, wf_tile_kernel)
+#undef P3D_DEFINE_SELECTOR
+
+static const void* tree_fn(bool count, bool lds, int occ, bool grid) {
+    if (grid) return count ? (lds ? fn_ptr(whitted_tree_kernel<true, true, 1, true>) : fn_ptr(whitted_tree_kernel<true, false, 1, true>))
+                           : (lds ? fn_ptr(whitted_tree_kernel<false, true, 1, true>) : fn_ptr(whitted_tree_kernel<false, false, 1, true>));
+    if (count) return lds ? fn_ptr(whitted_tree_kernel<true, true, 1>) : fn_ptr(whitted_tree_kernel<true, false, 1>);
+    if (occ == 5) return lds ? fn_ptr(whitted_tree_kernel<false, true, 5>) : fn_ptr(whitted_tree_kernel<false, false, 5>);
+    if (occ == 6) return lds ? fn_ptr(whitted_tree_kernel<false, true, 6>) : fn_ptr(whitted_tree_kernel<false, false, 6>);
+    return lds ? fn_ptr(whitted_tree_kernel<false, true, 1>) : fn_ptr(whitted_tree_kernel<false, false, 1>);
+}
+static hipError_t launch_by_pointer(const void* fn, const LaunchParams& P, dim3 grid, dim3 block, size_t shmem, hipStream_t stream) {
+    LaunchParams Pc = P;
+    void* args[] = {&Pc};
+    return hipLaunchKernel(fn, grid, block, args, shmem, stream);
+}
 
 hipError_t launch_tree(const LaunchParams& P, bool count, bool lds, int occ, hipStream_t stream) {
-    dim3 grid((unsigned)P.grid_blocks), block(64 * P.wg_waves);
-    size_t shmem = tree_kernel_lds_bytes(P, lds);
-    if (count) {
-        if (lds) hipLaunchKernelGGL((whitted_tree_kernel<true, true, 1>), grid, block, shmem, stream, P);
-        else hipLaunchKernelGGL((whitted_tree_kernel<true, false, 1>), grid, block, shmem, stream, P);
-    } else if (lds) P3D_LAUNCH_OCC(whitted_tree_kernel, occ, grid, block, shmem, stream, P, true);
-    else P3D_LAUNCH_OCC(whitted_tree_kernel, occ, grid, block, shmem, stream, P, false);
-    return hipGetLastError();
+    return launch_by_pointer(tree_fn(count, lds, occ, P.accel == 1), P, dim3((unsigned)P.grid_blocks), dim3(64 * P.wg_waves),
+                             tree_kernel_lds_bytes(P, lds), stream);
 }
-
-// wavefront level kernels: {count} x {scene in LDS} x {packet walk}
-#define P3D_LAUNCH_WF(KERNEL, count, lds, packet, occ, grid, block, shmem, stream, P)                 \
-    do {                                                                                             \
-        if (count) {                                                                                 \
-            if (lds) { if (packet) hipLaunchKernelGGL((KERNEL<true, true, true, 1>), grid, block, shmem, stream, P);   \
-                       else hipLaunchKernelGGL((KERNEL<true, true, false, 1>), grid, block, shmem, stream, P); }       \
-            else { if (packet) hipLaunchKernelGGL((KERNEL<true, false, true, 1>), grid, block, shmem, stream, P);      \
-                   else hipLaunchKernelGGL((KERNEL<true, false, false, 1>), grid, block, shmem, stream, P); }          \
-        } else if (lds) {                                                                            \
-            if (packet) P3D_LAUNCH_OCC(KERNEL, occ, grid, block, shmem, stream, P, true, true);      \
-            else P3D_LAUNCH_OCC(KERNEL, occ, grid, block, shmem, stream, P, true, false);            \
-        } else {                                                                                     \
-            if (packet) P3D_LAUNCH_OCC(KERNEL, occ, grid, block, shmem, stream, P, false, true);     \
-            else P3D_LAUNCH_OCC(KERNEL, occ, grid, block, shmem, stream, P, false, false);           \
-        }                                                                                            \
-    } while (0)
-
-// the variants with random draws (P.features != 0): default register budget only
-#define P3D_LAUNCH_WF_STOCH(KERNEL, count, lds, packet, grid, block, shmem, stream, P)                \
-    do {                                                                                             \
-        if (count) {                                                                                 \
-            if (lds) { if (packet) hipLaunchKernelGGL((KERNEL<true, true, true, 1, true>), grid, block, shmem, stream, P);   \
-                       else hipLaunchKernelGGL((KERNEL<true, true, false, 1, true>), grid, block, shmem, stream, P); }       \
-            else { if (packet) hipLaunchKernelGGL((KERNEL<true, false, true, 1, true>), grid, block, shmem, stream, P);      \
-                   else hipLaunchKernelGGL((KERNEL<true, false, false, 1, true>), grid, block, shmem, stream, P); }          \
-        } else {                                                                                     \
-            if (lds) { if (packet) hipLaunchKernelGGL((KERNEL<false, true, true, 1, true>), grid, block, shmem, stream, P);  \
-                       else hipLaunchKernelGGL((KERNEL<false, true, false, 1, true>), grid, block, shmem, stream, P); }      \
-            else { if (packet) hipLaunchKernelGGL((KERNEL<false, false, true, 1, true>), grid, block, shmem, stream, P);     \
-                   else hipLaunchKernelGGL((KERNEL<false, false, false, 1, true>), grid, block, shmem, stream, P); }         \
-        }                                                                                            \
-    } while (0)
-
-hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, bool packet, int occ, hipStream_t stream) {
-    dim3 grid((unsigned)P.grid_blocks), block(64 * P.wg_waves);
-    if (P.features) P3D_LAUNCH_WF_STOCH(wf_primary_kernel, count, lds, packet, grid, block, wavefront_lds_bytes(P, lds), stream, P);
-    else P3D_LAUNCH_WF(wf_primary_kernel, count, lds, packet, occ, grid, block, wavefront_lds_bytes(P, lds), stream, P);
-    return hipGetLastError();
+hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, int walk, int occ, hipStream_t stream) {
+    return launch_by_pointer(wf_primary_fn(count, lds, walk, occ, P.features != 0), P, dim3((unsigned)P.grid_blocks),
+                             dim3(64 * P.wg_waves), wavefront_lds_bytes(P, lds), stream);
 }
-hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, bool packet, int occ, unsigned waves,
+hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, int walk, int occ, unsigned waves,
                                hipStream_t stream) {
-    dim3 grid((waves + P.wg_waves - 1) / P.wg_waves), block(64 * P.wg_waves);
-    if (P.features) P3D_LAUNCH_WF_STOCH(wf_secondary_kernel, count, lds, packet, grid, block, wavefront_lds_bytes(P, lds), stream, P);
-    else P3D_LAUNCH_WF(wf_secondary_kernel, count, lds, packet, occ, grid, block, wavefront_lds_bytes(P, lds), stream, P);
-    return hipGetLastError();
+    return launch_by_pointer(wf_secondary_fn(count, lds, walk, occ, P.features != 0), P, dim3((waves + P.wg_waves - 1) / P.wg_waves),
+                             dim3(64 * P.wg_waves), wavefront_lds_bytes(P, lds), stream);
 }
+// waves of the deeper-level kernel that can be resident on the device at once (LDS-scene variants: 256-thread workgroups)
+hipError_t wf_resident_waves(const LaunchParams& P, bool primary, bool count, bool lds, int walk, int occ, unsigned* waves) {
+    const void* fn = primary ? wf_primary_fn(count, lds, walk, occ, P.features != 0) : wf_secondary_fn(count, lds, walk, occ, P.features != 0);
+    int per_cu = 0, dev = 0, cus = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * P.wg_waves, wavefront_lds_bytes(P, lds));
+    if (e != hipSuccess) return e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    *waves = (unsigned)((per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1) * P.wg_waves);
+    return hipSuccess;
+}
+// tile schedule: 256-thread workgroups
+size_t tile_kernel_lds_bytes(const LaunchParams& P, bool lds) {
+    return scene_lds_bytes(P, lds) + (size_t)P.trav_stack_dwords * 4 * 4 + sizeof(TileLds);
+}
+// workgroups of this variant that can be resident on the whole device (persistent grid size)
+hipError_t tile_kernel_resident_blocks(const LaunchParams& P, bool count, bool lds, int walk, int occ, int* blocks) {
+    const void* fn = wf_tile_fn(count, lds, walk, occ, P.features != 0);
+    const size_t shmem = tile_kernel_lds_bytes(P, lds);
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    int per_cu = 0, dev = 0, cus = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, shmem);
+    if (e != hipSuccess) return e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    *blocks = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    return hipSuccess;
+}
+hipError_t launch_wf_tile(const LaunchParams& P, bool count, bool lds, int walk, int occ, unsigned blocks, hipStream_t stream) {
+    return launch_by_pointer(wf_tile_fn(count, lds, walk, occ, P.features != 0), P, dim3(blocks), dim3(256),
+                             tile_kernel_lds_bytes(P, lds), stream);
+}
+
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream) {
     hipLaunchKernelGGL(wf_resolve_kernel, dim3(blocks), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
+
+__global__ void clear_words_kernel(uint32_t* p, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+}
+hipError_t launch_clear_words(uint32_t* p, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(clear_words_kernel, dim3((n + 255) / 256 < 64 ? (n + 255) / 256 : 64), dim3(256), 0, stream, p, n);
     return hipGetLastError();
 }
 
@@ -625,10 +882,8 @@ hipError_t launch_sum_samples(const LaunchParams& P, size_t first_px, size_t n_p
 
 hipError_t prepare_kernels(size_t max_lds) {
     // only the tree kernel without an LDS scene copy can need more than the 64 KiB default
-    const void* fns[] = {reinterpret_cast<const void*>(whitted_tree_kernel<true, false, 1>),
-                         reinterpret_cast<const void*>(whitted_tree_kernel<false, false, 1>),
-                         reinterpret_cast<const void*>(whitted_tree_kernel<false, false, 5>),
-                         reinterpret_cast<const void*>(whitted_tree_kernel<false, false, 6>)};
+    const void* fns[] = {tree_fn(true, false, 1, false), tree_fn(false, false, 1, false), tree_fn(false, false, 5, false),
+                         tree_fn(false, false, 6, false), tree_fn(true, false, 1, true), tree_fn(false, false, 1, true)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
         if (e != hipSuccess) return e;

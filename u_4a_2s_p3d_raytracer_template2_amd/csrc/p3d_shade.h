@@ -49,29 +49,32 @@ __device__ __forceinline__ Mtl load_material(const SV& sv, uint32_t m) {
 
 
 // Traversal context of a lane: its private stack (per-lane walk) and its wave's shared stack
-// (packet walk).  PACKET selects the walk at compile time; results are identical.
+// (packet walk).  WALK selects the walk at compile time: 0 = per-lane BVH walk, 1 = wave-wide (packet) BVH
+// walk -- identical results -- and 2 = the reference's uniform grid (GRID mode, accel 1: its own semantics).
 struct TravCtx { TravStack lane; WaveStack wave; };
+enum { WALK_LANE = 0, WALK_PACKET = 1, WALK_GRID = 2 };
 
-template <bool COUNT, bool PACKET, class SV>
+template <bool COUNT, int WALK, class SV>
 __device__ __forceinline__ Hit find_closest(const LaunchParams& P, const SV& sv, const Ray& ray, bool active,
                                             const TravCtx& tc, Ctr& ctr) {
-    if (PACKET) return closest_hit_packet<COUNT>(P, sv, ray, active, tc.wave, ctr);
+    if (WALK == WALK_PACKET) return closest_hit_packet<COUNT>(P, sv, ray, active, tc.wave, ctr);
     Hit h; h.t = 3.402823466e+38f; h.ref = 0xFFFFFFFFu; h.sid = 0xFFFFFFFFu; h.mat = 0;
-    if (active) h = closest_hit<COUNT>(P, sv, ray, tc.lane, ctr);
+    if (active) h = (WALK == WALK_GRID) ? grid_closest<COUNT>(P, sv, ray, ctr) : closest_hit<COUNT>(P, sv, ray, tc.lane, ctr);
     return h;
 }
 
 // Shadow query of processLight() (RT/main.cpp:476-510).  `need` = this lane builds a shadow
 // ray (L.N > 0).  NONE: un-normalised direction, no distance bound; BVH/GRID: normalised
 // direction and t < |L| (BVH::Traverse(Ray&), RT/bvh.cpp:351-352).
-template <bool COUNT, bool PACKET, class SV>
+template <bool COUNT, int WALK, class SV>
 __device__ __forceinline__ bool light_occluded(const LaunchParams& P, const SV& sv, V3 L, V3 precise, bool need,
                                                const TravCtx& tc, Ctr& ctr) {
     Ray sr; sr.o = precise; sr.d = L;
     float length = 0.0f;
-    const bool bounded = P.accel != 0;
+    const bool bounded = WALK == WALK_GRID || P.accel != 0;
     if (bounded && need) { length = vlen(sr.d); sr.d = normalized(sr.d); }
-    if (PACKET) return any_hit_packet<COUNT>(P, sv, sr, need, bounded, length, tc.wave, ctr);
+    if (WALK == WALK_PACKET) return any_hit_packet<COUNT>(P, sv, sr, need, bounded, length, tc.wave, ctr);
+    if (WALK == WALK_GRID) return need ? grid_any<COUNT>(P, sv, sr, length, ctr) : false;   // Grid::Traverse(Ray&), RT/grid.cpp:313
     return need ? any_hit<COUNT>(P, sv, sr, bounded, length, tc.lane, ctr) : false;
 }
 // Blinn-Phong term of one unoccluded light, RT/main.cpp:512-525
@@ -126,9 +129,9 @@ constexpr uint32_t kRngRefl = 0xA511E9B3u, kRngRefr = 0x63D83595u, kRngFuzzy = 0
 // area light, one stratum per pixel sample, when soft shadows run with anti-aliasing
 // (RT/main.cpp:621); the light's own position otherwise
 template <bool STOCH>
-__device__ __forceinline__ V3 light_position(const LaunchParams& P, float4 lpos, uint32_t light, uint32_t rng) {
+__device__ __forceinline__ V3 light_position(const LaunchParams& P, float4 lpos, uint32_t light, uint32_t rng, int sample) {
     if (STOCH && (P.features & kFeatSoftJitter)) {
-        const float offx = (float)(P.wf_sample / P.spp), offy = (float)(P.wf_sample % P.spp);   // RT/main.cpp:779-780
+        const float offx = (float)(sample / P.spp), offy = (float)(sample % P.spp);   // RT/main.cpp:779-780
         const float jx = fdiv(offx + rng_u01(rng, 2u * light), (float)P.spp);
         const float jy = fdiv(offy + rng_u01(rng, 2u * light + 1u), (float)P.spp);
         return mk(lpos.x + 0.5f * jx, lpos.y + 0.5f * jy, lpos.z);
@@ -147,10 +150,13 @@ __device__ __forceinline__ V3 combine_node(V3 color, float KR, V3 spec, V3 refl_
 // the shadow queries sit in wave-uniform control flow (the packet walk needs every lane of the
 // wave to arrive together): lanes without a ray or without a hit carry live == false /
 // hit == false through the light loop instead of leaving early.
-template <bool COUNT, bool PACKET, class SV, bool STOCH = false>
+template <bool COUNT, int WALK, class SV, bool STOCH = false>
 __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv, const Ray& ray, const Hit& h,
                                              bool live, int depth, float ior_1, const TravCtx& tc, Ctr& ctr,
-                                             uint32_t rng = 0u) {
+                                             uint32_t rng = 0u, int sample_override = -1) {
+    // pixel sample this invocation belongs to: a launch parameter in the wavefront schedule (one launch per
+    // sample pass), a loop variable in the tile schedule
+    const int sample = sample_override >= 0 ? sample_override : P.wf_sample;
     NodeOut o;
     o.terminal = true; o.KR = 0.0f; o.mat = h.mat; o.has_refl = false; o.has_refr = false; o.newIor = 1.0f;
     o.rng_refl = STOCH ? rng_mix(rng, kRngRefl) : 0u; o.rng_refr = STOCH ? rng_mix(rng, kRngRefr) : 0u;
@@ -178,9 +184,9 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
         uint64_t occluded = 0;
         for (uint32_t i = 0; i < ln; i++) {
             const float4 lpos = reinterpret_cast<const float4*>(P.lights + l0 + i)[0];
-            V3 L = sub(light_position<STOCH>(P, lpos, l0 + i, rng), hit_point);
+            V3 L = sub(light_position<STOCH>(P, lpos, l0 + i, rng, sample), hit_point);
             const bool need = hit && dot(L, normal) > 0.0f;              // RT/main.cpp:476
-            if (light_occluded<COUNT, PACKET>(P, sv, L, precise, need, tc, ctr)) occluded |= (1ull << i);
+            if (light_occluded<COUNT, WALK>(P, sv, L, precise, need, tc, ctr)) occluded |= (1ull << i);
         }
         if (hit) {
             Mtl Ml = load_material(sv, h.mat);
@@ -188,7 +194,7 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
                 if (occluded & (1ull << i)) continue;
                 const float4* lp = reinterpret_cast<const float4*>(P.lights + l0 + i);
                 float4 lpos = lp[0], lcol = lp[1];
-                V3 L = sub(light_position<STOCH>(P, lpos, l0 + i, rng), hit_point);
+                V3 L = sub(light_position<STOCH>(P, lpos, l0 + i, rng, sample), hit_point);
                 light_term(L, mk(lcol.x, lcol.y, lcol.z), color, Ml, ray, normal);
             }
         }

@@ -317,6 +317,141 @@ __device__ __forceinline__ bool any_hit(const LaunchParams& P, const SV& sv, con
 }
 
 
+// ------------------------------------------------------------------ uniform grid (accel 1, RT/grid.cpp)
+// The reference's GRID mode is NOT "the same hits through another structure": Grid::Traverse finds the
+// closest hit PER CELL and accepts it only if it lies before the cell's exit (RT/grid.cpp:265-309), planes
+// sit in the cells their default [-1,1]^3 box covers and are no closest-hit candidates anywhere
+// else, and a shadow ray that misses the grid's box counts as SHADOWED (RT/grid.cpp:327-328).  So GRID mode
+// walks a real grid here: the reference's cell-count formula and cell lists (built by grid_builder.cpp with
+// the reference's float arithmetic), its slab clip and Amanatides-Woo set-up evaluated in the same order --
+// the DDA state in double precision like the reference's -- and, per cell, the primitives in scene order.
+// Per lane: cells are a few primitives each and rays diverge after the first step.
+template <bool COUNT, class SV>
+__device__ __forceinline__ bool prim_test(const LaunchParams& P, const SV& sv, const Ray& r, uint32_t ref, float& t,
+                                          uint32_t& sid, uint32_t& mat, Ctr& ctr) {
+    const uint32_t kind = ref >> kRefKindShift, idx = ref & kRefIndexMask;
+    if (kind == 1u) {
+        float4 a, b, c;
+        sv_tri(sv, idx, a, b, c);
+        if (COUNT) ctr.tri++;
+        sid = __float_as_uint(a.w); mat = __float_as_uint(b.w);
+        return hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
+    } else if (kind == 0u) {
+        const float4 s = sv_sphere(sv, idx);
+        const PrimMeta m = sv_sphere_meta(sv, idx);
+        if (COUNT) ctr.sph++;
+        sid = m.scene_id; mat = m.material;
+        return hit_sphere(r, mk(s.x, s.y, s.z), s.w, t);
+    } else if (kind == 2u) {
+        float4 a, b; V3 nn;
+        sv_box(sv, idx, a, b);
+        if (COUNT) ctr.aab++;
+        sid = __float_as_uint(a.w); mat = __float_as_uint(b.w);
+        return hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
+    }
+    const PlaneRec pl = P.planes[idx];
+    const PrimMeta m = P.plane_meta[idx];
+    if (COUNT) ctr.pln++;
+    sid = m.scene_id; mat = m.material;
+    return hit_plane(r, mk(pl.nx, pl.ny, pl.nz), pl.d, t);
+}
+
+struct GridWalk {
+    int ix, iy, iz, ix_step, iy_step, iz_step, ix_stop, iy_stop, iz_stop;
+    double tx_next, ty_next, tz_next, dtx, dty, dtz;
+};
+__device__ __forceinline__ int grid_index(float v, int n) {                // (int)clamp(v, 0, n - 1), RT/maths.h:50-53
+    const double x = (double)v, hi = (double)(n - 1);
+    return (int)(x < 0.0 ? 0.0 : (x > hi ? hi : x));
+}
+// Grid::Init_Traverse, RT/grid.cpp:101-245.  false = the ray misses the grid's bounding box.
+__device__ __forceinline__ bool grid_init(const LaunchParams& P, const Ray& ray, GridWalk& g) {
+    const float ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+    const float x0 = P.grid_min[0], y0 = P.grid_min[1], z0 = P.grid_min[2];
+    const float x1 = P.grid_max[0], y1 = P.grid_max[1], z1 = P.grid_max[2];
+    const int nx = P.grid_n[0], ny = P.grid_n[1], nz = P.grid_n[2];
+    float tx_min, ty_min, tz_min, tx_max, ty_max, tz_max, t0, t1;
+    const float a = fdiv(1.0f, dx);
+    if (a >= 0.0f) { tx_min = (x0 - ox) * a; tx_max = (x1 - ox) * a; } else { tx_min = (x1 - ox) * a; tx_max = (x0 - ox) * a; }
+    const float b = fdiv(1.0f, dy);
+    if (b >= 0.0f) { ty_min = (y0 - oy) * b; ty_max = (y1 - oy) * b; } else { ty_min = (y1 - oy) * b; ty_max = (y0 - oy) * b; }
+    const float c = fdiv(1.0f, dz);
+    if (c >= 0.0f) { tz_min = (z0 - oz) * c; tz_max = (z1 - oz) * c; } else { tz_min = (z1 - oz) * c; tz_max = (z0 - oz) * c; }
+    if (tx_min > ty_min) t0 = tx_min; else t0 = ty_min;
+    if (tz_min > t0) t0 = tz_min;
+    if (tx_max < ty_max) t1 = tx_max; else t1 = ty_max;
+    if (tz_max < t1) t1 = tz_max;
+    if (t0 > t1 || t1 < 0.0f) return false;
+    const bool inside = (ox > x0 && ox < x1) && (oy > y0 && oy < y1) && (oz > z0 && oz < z1);   // AABB::isInside (strict)
+    float px = ox, py = oy, pz = oz;
+    if (!inside) { px = ox + dx * t0; py = oy + dy * t0; pz = oz + dz * t0; }
+    g.ix = grid_index(fdiv((px - x0) * (float)nx, x1 - x0), nx);
+    g.iy = grid_index(fdiv((py - y0) * (float)ny, y1 - y0), ny);
+    g.iz = grid_index(fdiv((pz - z0) * (float)nz, z1 - z0), nz);
+    g.dtx = (double)fdiv(tx_max - tx_min, (float)nx);
+    g.dty = (double)fdiv(ty_max - ty_min, (float)ny);
+    g.dtz = (double)fdiv(tz_max - tz_min, (float)nz);
+    if (dx > 0.0f) { g.tx_next = (double)tx_min + (double)(g.ix + 1) * g.dtx; g.ix_step = 1; g.ix_stop = nx; }
+    else           { g.tx_next = (double)tx_min + (double)(nx - g.ix) * g.dtx; g.ix_step = -1; g.ix_stop = -1; }
+    if (dx == 0.0f) g.tx_next = (double)3.402823466e+38f;
+    if (dy > 0.0f) { g.ty_next = (double)ty_min + (double)(g.iy + 1) * g.dty; g.iy_step = 1; g.iy_stop = ny; }
+    else           { g.ty_next = (double)ty_min + (double)(ny - g.iy) * g.dty; g.iy_step = -1; g.iy_stop = -1; }
+    if (dy == 0.0f) g.ty_next = (double)3.402823466e+38f;
+    if (dz > 0.0f) { g.tz_next = (double)tz_min + (double)(g.iz + 1) * g.dtz; g.iz_step = 1; g.iz_stop = nz; }
+    else           { g.tz_next = (double)tz_min + (double)(nz - g.iz) * g.dtz; g.iz_step = -1; g.iz_stop = -1; }
+    if (dz == 0.0f) g.tz_next = (double)3.402823466e+38f;
+    return true;
+}
+// one DDA step (RT/grid.cpp:282-308 without the acceptance test): returns the exit distance of the cell
+// being left in t_exit, false when the walk leaves the grid
+__device__ __forceinline__ bool grid_step(GridWalk& g) {
+    if (g.tx_next < g.ty_next && g.tx_next < g.tz_next) { g.tx_next += g.dtx; g.ix += g.ix_step; return g.ix != g.ix_stop; }
+    if (g.ty_next < g.tz_next) { g.ty_next += g.dty; g.iy += g.iy_step; return g.iy != g.iy_stop; }
+    g.tz_next += g.dtz; g.iz += g.iz_step; return g.iz != g.iz_stop;
+}
+__device__ __forceinline__ double grid_cell_exit(const GridWalk& g) {
+    if (g.tx_next < g.ty_next && g.tx_next < g.tz_next) return g.tx_next;
+    if (g.ty_next < g.tz_next) return g.ty_next;
+    return g.tz_next;
+}
+// Grid::Traverse(Ray&, Object**, Vector&), RT/grid.cpp:248-310
+template <bool COUNT, class SV>
+__device__ __forceinline__ Hit grid_closest(const LaunchParams& P, const SV& sv, const Ray& r, Ctr& ctr) {
+    Hit best; best.t = 3.402823466e+38f; best.ref = 0xFFFFFFFFu; best.sid = 0xFFFFFFFFu; best.mat = 0;
+    if (COUNT) ctr.closest++;
+    GridWalk g;
+    if (!grid_init(P, r, g)) return best;
+    for (;;) {
+        const uint32_t cell = (uint32_t)g.ix + (uint32_t)P.grid_n[0] * ((uint32_t)g.iy + (uint32_t)P.grid_n[1] * (uint32_t)g.iz);
+        const uint32_t i0 = P.grid_cells[cell], i1 = P.grid_cells[cell + 1];
+        Hit c = best; c.t = 3.402823466e+38f;                   // closestDistance restarts in every cell
+        for (uint32_t i = i0; i < i1; i++) {                    // scene order inside a cell: "distance < closestDistance"
+            const uint32_t ref = P.grid_items[i];
+            float t; uint32_t sid, mat;
+            if (prim_test<COUNT>(P, sv, r, ref, t, sid, mat, ctr) && t < c.t) { c.t = t; c.ref = ref; c.sid = sid; c.mat = mat; }
+        }
+        if ((double)c.t < grid_cell_exit(g)) return c;           // accepted only before the cell's exit
+        if (!grid_step(g)) return best;
+    }
+}
+// Grid::Traverse(Ray&), RT/grid.cpp:313-361: r.d is normalised, length = |L|.  A ray that misses the
+// grid's box is reported as occluded, like in the reference.
+template <bool COUNT, class SV>
+__device__ __forceinline__ bool grid_any(const LaunchParams& P, const SV& sv, const Ray& r, float length, Ctr& ctr) {
+    if (COUNT) ctr.shadow++;
+    GridWalk g;
+    if (!grid_init(P, r, g)) return true;
+    for (;;) {
+        const uint32_t cell = (uint32_t)g.ix + (uint32_t)P.grid_n[0] * ((uint32_t)g.iy + (uint32_t)P.grid_n[1] * (uint32_t)g.iz);
+        const uint32_t i0 = P.grid_cells[cell], i1 = P.grid_cells[cell + 1];
+        for (uint32_t i = i0; i < i1; i++) {
+            float t; uint32_t sid, mat;
+            if (prim_test<COUNT>(P, sv, r, P.grid_items[i], t, sid, mat, ctr) && t < length) return true;
+        }
+        if (!grid_step(g)) return false;
+    }
+}
+
 // ------------------------------------------------------------------ wave-wide (packet) traversal
 // For small trees the 64 rays of a wave walk the BVH TOGETHER: the node index is wave-uniform,
 // so node and primitive records are fetched once per wave (broadcast LDS reads or scalar
