@@ -1,29 +1,41 @@
 #!/usr/bin/env python3
-"""bench.py -- Mrays/s of the Whitted hot path on BASELINE config 2
-(mount_low.p3f, 1920x1080, depth 4, BVH), one process per GPU.
+"""bench.py -- Mrays/s of the Whitted hot path, one process per GPU.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W                        (BASELINE config 2, the headline)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = `--frames-per-step` frames of the configuration's camera, each rendered by the HIP
-kernel into HBM-resident buffers.  With N > 1 every frame is split into interleaved 16-row
-blocks across the ranks (total work fixed: strong scaling) and each step ends with ONE RCCL
-gather of the compact tile buffers to rank 0 plus the de-interleave kernel there.  The gather of
-step i is waited for while step i+1 renders into a second set of tile buffers (--gather sync waits
-at once); every step's frames are on rank 0 when the timed region closes.
-value = rays of all frames / max-over-ranks wall time; a ray is one closest-hit or one shadow
-query, counted by the counting build of the same kernel on the same frame.
+Workloads (--workload):
+  config2    mount_low.p3f 1920x1080 depth 4 BVH -- the configuration BASELINE.json's metric is quoted on.
+             A step = --frames-per-step frames into HBM-resident buffers, --frames-in-flight of them overlapped
+             (independent frames on separate scene handles / HIP streams, like the reference's render-another-
+             image loop).
+  config4    mount_low.p3f 4096x4096 depth 6, 2x2 jittered samples + thin lens (BASELINE config 4): one frame per
+             step, the sample array uploaded once.
+  synthetic  the SURVEY 8d scaling scene (--prims random spheres + triangles, BVH read from HBM).
+  pathtracer BASELINE config 5 (P3D_RT.glsl), samples split over the ranks.
 
-A frame is the wavefront schedule: wf_primary_kernel (camera rays + their shadow rays +
-shading), one wf_secondary_kernel per deeper tree level, and the resolve passes.
+N > 1: every frame is cut into interleaved 16-row blocks (p3d_render rank / world: total work fixed, strong
+scaling); each step ends with ONE gather of the compact tile buffers to rank 0 THROUGH THE C-ABI (p3d_gather:
+grouped ncclSend / ncclRecv over RCCL, include/p3d_hip.h) on a communication stream, plus p3d_deinterleave_frames
+there; with two tile-buffer sets the gather of step i overlaps the rendering of step i + 1 (--gather sync: one
+set).  torch.distributed (gloo) only carries the 128-byte communicator id, the barrier and the timing reduction.
+value = rays of all frames / max-over-ranks wall time; a ray is one closest-hit or one shadow query,
+counted by the counting build of the same kernels on the same frame.
 
-Extra objects on the JSON line: "roofline" for the dominant kernel wf_primary_kernel
-(algorithmic bytes of ITS launch -- counted by the counting build run at depth 1, which is
-exactly the level-1 work -- divided by its mean duration from HIP events on the launch
-stream, vs the 8 TB/s HBM peak; traffic = PMC-measured HBM bytes per launch from
-profiles/) and, at N=1, "cpu_baseline" (the CPU oracle timed on this box's host cores).
+Extra objects on the JSON line:
+  "roofline"     for the ray kernel with the most device time (from the rocprofv3 kernel stats committed under
+                 profiles/, see profiles/current.json).  The 12-primitive scene lives in LDS, so HBM is not what
+                 binds these kernels: the bound is VECTOR-INSTRUCTION ISSUE (one wave-instruction per 2 cycles per
+                 SIMD, measured: profiles/r02_valu_rate_ubench.txt); achieved = SQ_INSTS_VALU per launch / its
+                 duration.  Scalar-unit load, the SURVEY 8d algorithmic-bytes figure and the PMC-measured HBM
+                 traffic are reported next to it.  Every number can be recomputed from the files named in
+                 roofline.source; roofline.kernel_ms_live is this run's own HIP-event duration of that kernel.
+  "cpu_baseline" at N = 1: the REFERENCE's own object code (oracle/_ref, built from /root/reference in the build
+                 container and carried as a .so) rendering whole frames of the same configuration on one host
+                 core -- the reference is single-threaded; the oracle port on all cores is reported beside it.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -35,48 +47,83 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-RES = (1920, 1080)
-MAX_DEPTH = 4
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CLOCK_GHZ = 2.4                  # max shader clock (MI355X_MICROARCH.md)
+N_SIMD, N_CU = 1024, 256
+VALU_CYCLES_PER_INST = 2.0       # one wave64 VALU instruction per 2 cycles per SIMD (measured, ubench)
 ROW_BLOCK = 16
 
+WORKLOADS = {
+    "config2": dict(scene="mount_low", res=(1920, 1080), depth=4, spp=0, frames=12,
+                    name="mount_low.p3f 1920x1080 depth 4 BVH (BASELINE config 2)"),
+    "config4": dict(scene="mount_low", res=(4096, 4096), depth=6, spp=2, frames=1, cpu_res=(1024, 1024),
+                    name="mount_low.p3f 4096x4096 depth 6, 2x2 samples + thin lens (BASELINE config 4)"),
+    "synthetic": dict(scene=None, res=(1920, 1080), depth=4, spp=0, frames=12, name=None),
+}
 
-def cpu_baseline(scene_file, budget_s=20.0):
-    """The oracle (CPU restatement of the reference, incl. the brute-force fall-through of
-    SURVEY Q1) single-threaded on full config-2 frames, plus the break-fixed multi-threaded
-    variant as the honest strong baseline.  Checker-only code: never on the product path."""
+
+def kernel_source_digest():
+    """sha256 over the kernel sources: profiles taken from other kernels are flagged as stale."""
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "u_4a_2s_p3d_raytracer_template2_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(scene_file, res, depth, spp, budget_s=20.0):
+    """Whole frames of the configuration on ONE host core by the reference's own object code (oracle/_ref);
+    the oracle port (same structure, checked bit for bit against it) when the .so did not travel.  Plus the
+    oracle with the fall-through removed on all cores.  Checker-only code: never on the product path."""
     from oracle import oracle_py as O
+    from oracle import ref_py as R
     sc = O.Scene(scene_file)
-    sc.set_resolution(*RES)
-    times, rays = [], 0
+    sc.set_resolution(*res)
+    times, rays, kind = [], 0, "port"
     t_start = time.time()
-    while len(times) < 5 and (time.time() - t_start) < budget_s * 0.6:
-        t0 = time.perf_counter()
-        r = sc.render(max_depth=MAX_DEPTH, accel=2, threads=1, want_f32=False, want_hit=False)
-        times.append(time.perf_counter() - t0)
-        rays = r["counters"]["rays"]
+    if R.available(depth):
+        kind = "reference"
+        rs = R.RefScene.from_oracle_scene(sc, scene_file, res=res, depth=depth)
+        while len(times) < 5 and (time.time() - t_start) < budget_s * 0.6:
+            t0 = time.perf_counter()
+            r = rs.render(2, spp, 12345)
+            times.append(time.perf_counter() - t0)
+            rays = r["rays"]
+            if times[-1] > budget_s * 0.3:
+                break
+        rs.close()
+    else:
+        while len(times) < 5 and (time.time() - t_start) < budget_s * 0.6:
+            t0 = time.perf_counter()
+            r = sc.render(max_depth=depth, accel=2, spp=spp, threads=1, want_f32=False, want_hit=False)
+            times.append(time.perf_counter() - t0)
+            rays = r["counters"]["rays"]
+            if times[-1] > budget_s * 0.3:
+                break
     st = float(np.median(times))
-    ncpu = os.cpu_count() or 1
-    mt_times = []
-    while len(mt_times) < 5 and (time.time() - t_start) < budget_s:
-        t0 = time.perf_counter()
-        sc.render(max_depth=MAX_DEPTH, accel=2, threads=ncpu, break_fixed=1, want_f32=False, want_hit=False)
-        mt_times.append(time.perf_counter() - t0)
-    out = {"value": rays / st / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-           "sample": "%d full 1920x1080 depth-4 frames, single thread, reference structure "
-                     "(BVH traversal + brute-force fall-through); median %.3f s/frame" % (len(times), st)}
-    if mt_times:
-        mt = float(np.median(mt_times))
-        out["multithread"] = {"value": rays / mt / 1e6, "unit": "Mrays/s", "cores": ncpu,
-                              "note": "fall-through removed + row blocks over all host cores; median %.4f s/frame" % mt}
+    out = {"value": rays / st / 1e6, "unit": "Mrays/s", "cores": 1, "kind": kind,
+           "sample": "%d full %dx%d depth-%d%s frame(s) on one core by %s (BVH traversal + the brute-force "
+                     "fall-through of SURVEY Q1); median %.3f s/frame" % (
+                         len(times), res[0], res[1], depth, " spp %d" % spp if spp else "",
+                         "the reference's own object code (oracle/_ref)" if kind == "reference" else "the oracle port", st)}
+    if spp == 0:
+        ncpu = os.cpu_count() or 1
+        mt = []
+        while len(mt) < 3 and (time.time() - t_start) < budget_s:
+            t0 = time.perf_counter()
+            sc.render(max_depth=depth, accel=2, threads=ncpu, break_fixed=1, want_f32=False, want_hit=False)
+            mt.append(time.perf_counter() - t0)
+        if mt:
+            m = float(np.median(mt))
+            out["multithread"] = {"value": rays / m / 1e6, "unit": "Mrays/s", "cores": ncpu, "kind": "port",
+                                  "note": "oracle port, fall-through removed + row blocks over all host cores; median %.4f s/frame" % m}
     return out
 
 
-def cpu_baseline_synthetic(n_prims, budget_s=25.0):
-    """Synthetic scaling scene: the brute-force fall-through of the reference is O(N) per ray, so the
-    sample is a 96x54 frame (1/400 of the pixels) of the same scene, single-threaded with the reference
-    structure, plus the break-fixed all-core variant at 480x270.  Only up to 2e5 primitives (the oracle
-    reads .p3f text)."""
+def cpu_baseline_synthetic(n_prims, depth, budget_s=25.0):
+    """Synthetic scaling scene: the brute-force fall-through of the reference is O(N) per ray, so the sample is
+    a 96x54 frame (1/400 of the pixels) of the same scene.  Only up to 2e5 primitives (.p3f text)."""
     if n_prims > 200000:
         return {"value": None, "unit": "Mrays/s", "cores": 1, "kind": "port",
                 "sample": "not run: the oracle loads .p3f text and its reference-structure closest hit is O(N) per ray"}
@@ -87,27 +134,113 @@ def cpu_baseline_synthetic(n_prims, budget_s=25.0):
     SY.write_p3f(path, n_prims, 96, 54)
     sc = O.Scene(path)
     t0 = time.perf_counter()
-    r = sc.render(max_depth=MAX_DEPTH, accel=2, threads=1, want_f32=False, want_hit=False)
+    r = sc.render(max_depth=depth, accel=2, threads=1, want_f32=False, want_hit=False)
     st = time.perf_counter() - t0
-    out = {"value": r["counters"]["rays"] / st / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-           "sample": "one 96x54 depth-4 frame of the same scene, single thread, reference structure; %.2f s" % st}
-    if st < budget_s:
-        ncpu = os.cpu_count() or 1
-        sc.set_resolution(480, 270)
-        t0 = time.perf_counter()
-        r = sc.render(max_depth=MAX_DEPTH, accel=2, threads=ncpu, break_fixed=1, want_f32=False, want_hit=False)
-        mt = time.perf_counter() - t0
-        out["multithread"] = {"value": r["counters"]["rays"] / mt / 1e6, "unit": "Mrays/s", "cores": ncpu,
-                              "note": "fall-through removed (reference BVH only) + all host cores, 480x270; %.3f s" % mt}
+    return {"value": r["counters"]["rays"] / st / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": "one 96x54 depth-%d frame of the same scene, single thread, reference structure; %.2f s" % (depth, st)}
+
+
+def _kname(name):
+    """'void p3d::k<false, true, 1, 1, false>(p3d::LaunchParams)' -> 'p3d::k<false, true, 1, 1, false>'"""
+    name = name.strip()
+    if name.startswith("void "):
+        name = name[5:]
+    if name.endswith(")") and "(" in name:
+        name = name[:name.rindex("(")]
+    return name.strip()
+
+
+def load_profile(workload):
+    """(entry of profiles/current.json, kernel-stats rows, PMC summary) or Nones."""
+    try:
+        cur = json.load(open(os.path.join(REPO, "profiles", "current.json")))[workload]
+    except Exception:
+        return None, None, None
+    stats = pmc = None
+    try:
+        import csv
+        rows = list(csv.DictReader(open(os.path.join(REPO, "profiles", cur["kernel_stats"]))))
+        stats = [r for r in rows if "p3d::" in r.get("Name", "")]
+    except Exception:
+        pass
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", cur["pmc"])))
+    except Exception:
+        pass
+    return cur, stats, pmc
+
+
+def roofline_from_profiles(workload, live):
+    """The roofline object: see the module docstring.  `live` = this run's own measurements."""
+    cur, stats, pmc = load_profile(workload)
+    out = {"bound": "valu_issue", "achieved": None, "peak": N_SIMD * CLOCK_GHZ / VALU_CYCLES_PER_INST, "unit": "Gwave-instr/s",
+           "frac": None, "traffic": None, "kernel": live.get("kernel"), "kernel_ms_live": live.get("kernel_ms"),
+           "frame_device_ms_live": live.get("frame_ms"),
+           "algorithmic": {"bytes_per_frame": live.get("alg_bytes"), "GBps": live.get("alg_gbps"),
+                           "frac_of_hbm_peak": None if live.get("alg_gbps") is None else live["alg_gbps"] / HBM_PEAK_GBS,
+                           "note": "SURVEY 8d: 32 B per slab test + 16/48/32/16 B per sphere/triangle/box/plane test + 3 B per pixel, "
+                                   "counted by the counting build; the scene is served from LDS/L2, so this is NOT HBM traffic and "
+                                   "HBM is not the binding resource"},
+           "source": None, "stale": None}
+    if not (cur and stats and pmc):
+        out["note"] = "no profile registered in profiles/current.json for this workload: only live HIP-event timings"
+        return out
+    out["source"] = {"kernel_stats": "profiles/" + cur["kernel_stats"], "pmc": "profiles/" + cur["pmc"],
+                     "issue_rates": "profiles/r02_valu_rate_ubench.txt"}
+    if pmc.get("kernel_source_digest") is None:
+        out["stale"] = None
+    elif pmc["kernel_source_digest"] != kernel_source_digest():
+        out["stale"] = True
+    else:
+        out["stale"] = False
+    # the ray kernel with the most device time in the kernel stats of this workload
+    def total_ns(r):
+        return float(r.get("TotalDurationNs") or r.get("TotalDuration(ns)") or 0.0)
+    ray = [r for r in stats if "<true" not in r["Name"]] or stats        # not the counting builds (first template argument)
+    top = max(ray, key=total_ns)
+    kernels = {}
+    for r in ray:
+        name = r["Name"]
+        e = None
+        for k, v in pmc.get("kernels", {}).items():
+            if _kname(k) == _kname(name):
+                e = v
+        calls = float(r.get("Calls") or 1)
+        avg_us = total_ns(r) / calls / 1e3
+        k = {"calls": int(calls), "avg_us": avg_us, "share_of_device_time": float(r.get("Percentage") or 0.0) / 100.0}
+        if e and e.get("SQ_INSTS_VALU") and e.get("GRBM_GUI_ACTIVE"):
+            cyc = e["GRBM_GUI_ACTIVE"] / 8.0                      # summed over the 8 XCDs (MI355X_MICROARCH.md)
+            k.update({
+                "valu_issue_frac": e["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (N_SIMD * cyc),
+                "valu_busy_frac": e["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * cyc) if e.get("SQ_ACTIVE_INST_VALU") else None,
+                "salu_issue_frac": e["SQ_INSTS_SALU"] / (N_CU * cyc) if e.get("SQ_INSTS_SALU") else None,
+                "valu_per_wave": e["SQ_INSTS_VALU"] / e["SQ_WAVES"] if e.get("SQ_WAVES") else None,
+                "salu_per_wave": e["SQ_INSTS_SALU"] / e["SQ_WAVES"] if e.get("SQ_WAVES") and e.get("SQ_INSTS_SALU") else None,
+                "lane_utilisation": e.get("valu_lane_utilisation"),
+                "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch_corrected"),
+                "kernel_cycles": cyc,
+            })
+        kernels[_kname(name)] = k
+    out["kernels"] = kernels
+    tk = kernels[_kname(top["Name"])]
+    out["kernel"] = _kname(top["Name"])
+    out["kernel_us_profile"] = tk["avg_us"]
+    if tk.get("valu_issue_frac") is not None:
+        out["frac"] = min(tk["valu_issue_frac"], 1.0)
+        out["achieved"] = out["frac"] * out["peak"]
+        out["traffic"] = tk.get("hbm_bytes_per_launch")
+        if out["traffic"]:
+            out["hbm"] = {"GBps": out["traffic"] / (tk["avg_us"] * 1e-6) / 1e9,
+                          "frac_of_hbm_peak": out["traffic"] / (tk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          "note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch (gfx950 correction, separate passes): frame buffer + ray / node queues"}
     return out
 
 
-def bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, rehearsal):
+def bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, comm):
     """BASELINE config 5: the Shadertoy path tracer, 1920x1080, --spp samples per pixel per step.
-    One step = one converged image.  N > 1: rank r traces samples r, r+N, ... (weak in samples per
-    pixel would change the image, so the image is fixed: strong scaling) and the linear sums are
-    reduced to rank 0 with one RCCL reduce."""
-    W, H = RES
+    N > 1: rank r traces samples r, r+N, ... and the linear sums are added up on rank 0 with ONE
+    ncclReduce through the C-ABI (p3d_pt_reduce_sum)."""
+    W, H = 1920, 1080
     spp = args.spp
     if spp % world:
         raise SystemExit("--spp must be a multiple of --gpus")
@@ -118,19 +251,12 @@ def bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, rehears
     def step():
         pt.render_device(0, lin.data_ptr(), W, H, spp // world, first_frame=rank, frame_stride=world)
         if world > 1:
-            if rehearsal:
-                torch.cuda.synchronize()
-                h = lin.cpu()
-                dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
-                if rank == 0:
-                    lin.copy_(h)
-            else:
-                dist.reduce(lin, dst=0, op=dist.ReduceOp.SUM)
+            comm.pt_reduce_sum(pt, lin.data_ptr(), lin.numel())
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -140,8 +266,7 @@ def bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, rehears
         step()
     barrier()
     dt = time.perf_counter() - t0
-    red_dev = torch.device("cpu") if rehearsal else dev
-    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    tt = torch.tensor([dt], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt_max = float(tt.item())
@@ -155,7 +280,7 @@ def bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, rehears
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic: the procedural scene of GPU_PathTracer_template/P3D_RT.glsl (no mouse, iTime = k/60)",
             "config": {"workload": "P3D_RT.glsl path tracer 1920x1080 %d spp (BASELINE config 5)" % spp,
-                       "parallelism": "1 GPU" if world == 1 else "%d GPUs: samples split, RCCL sum-reduce to rank 0" % world,
+                       "parallelism": "1 GPU" if world == 1 else "%d GPUs: samples split, one ncclReduce(sum) to rank 0 through the C-ABI" % world,
                        "image_mean": float(img.mean().item())},
             "roofline": None,
         }
@@ -168,9 +293,6 @@ def bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, rehears
             line["cpu_baseline"] = {"value": w * h * n / el / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
                                     "sample": "%dx%d, %d samples per pixel, single thread: %.1f s" % (w, h, n, el)}
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     pt.close()
 
 
@@ -179,29 +301,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-step", type=int, default=12)
+    ap.add_argument("--workload", choices=["config2", "config4", "pathtracer", "synthetic"], default="config2")
+    ap.add_argument("--frames-per-step", type=int, default=0, help="frames of a step (default: 12, config4: 1)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="independent frames overlapped on separate HIP streams (each with its own scene handle "
-                         "and workspace); 1 = strictly one frame after the other; default 3 per GPU-th of a frame "
-                         "(3 on one GPU, min(frames-per-step, 3 N) when the frame is tiled over N GPUs)")
+                    help="independent frames overlapped on separate HIP streams (each with its own scene handle and "
+                         "workspace); 1 = strictly one frame after the other; default min(frames per step, 3 x N)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the frames of a step as ONE captured HIP graph instead of ~8 launches per frame "
-                         "(auto: use it when capture succeeds)")
+                    help="replay the frames of a step as ONE captured HIP graph (auto: when the frame is tiled over several GPUs)")
     ap.add_argument("--gather", choices=["pipelined", "sync"], default="pipelined",
-                    help="N > 1: wait for a step's gather (and de-interleave it) while the NEXT step renders into a "
-                         "second tile buffer, or right after the step")
+                    help="N > 1: two tile-buffer sets, so that a step's gather overlaps the next step's rendering, or one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["config2", "pathtracer", "synthetic"], default="config2",
-                    help="config2 = the headline Whitted frame; pathtracer = BASELINE config 5 (P3D_RT.glsl scene, "
-                         "1920x1080, --spp samples per step, samples split across ranks + RCCL sum-reduce); "
-                         "synthetic = the SURVEY 8d scaling scene (--prims random spheres+triangles, HBM-resident BVH), "
-                         "same camera / resolution / depth as config 2")
     ap.add_argument("--prims", type=int, default=1000000, help="synthetic workload: number of primitives")
-    ap.add_argument("--schedule", choices=["default", "wavefront", "tree"], default="default",
-                    help="force a kernel schedule (default: the library's choice)")
-    ap.add_argument("--pmc-json", default=None,
-                    help="PMC summary (tools/pmc_summary.py) to take roofline.traffic from; default: the committed one "
-                         "for the workload under profiles/")
+    ap.add_argument("--schedule", choices=["default", "wavefront", "tree", "tile"], default="default",
+                    help="force a kernel schedule (default: the library's measured choice)")
     ap.add_argument("--spp", type=int, default=256, help="pathtracer workload: samples (frames) per step")
     args = ap.parse_args()
 
@@ -209,7 +321,6 @@ def main():
     import torch.distributed as dist
     from conftest import scene_path
     import u_4a_2s_p3d_raytracer_template2_amd as P
-    from u_4a_2s_p3d_raytracer_template2_amd import multigpu as MG
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -220,48 +331,63 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # Rehearsal switch for a ONE-GPU box: P3D_BENCH_REHEARSAL=1 puts every rank on cuda:0 and moves
-    # the gather through host memory with gloo (RCCL refuses two ranks on one device).  It exercises
-    # the sharding / gather / de-interleave code path, not xGMI; numbers from it mean nothing.
-    rehearsal = os.environ.get("P3D_BENCH_REHEARSAL") == "1"
+    # Rehearsal switch for a ONE-GPU box (RCCL refuses two ranks on one device): P3D_BENCH_REHEARSAL=1 puts every
+    # rank on cuda:0 and moves the tile buffers through host memory with gloo instead of p3d_gather.  It exercises
+    # the sharding / buffer rotation / de-interleave code of the N > 1 path, not xGMI; its numbers mean nothing.
+    rehearsal = os.environ.get("P3D_BENCH_REHEARSAL") == "1" and world > 1
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    comm = None
+    if rehearsal:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
+        # control plane only: the communicator id, barriers and the timing reduction go through gloo;
+        # every byte of image data moves through p3d_gather (RCCL) below
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ident = [P.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        comm = P.Comm.create(ident[0], rank, world, local_rank)
 
     if args.workload == "pathtracer":
-        return bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, rehearsal)
+        if rehearsal:
+            raise SystemExit("the pathtracer workload has no rehearsal mode")
+        bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, comm)
+        if world > 1:
+            dist.barrier()
+            comm.close()
+            dist.destroy_process_group()
+        return
 
+    wl = WORKLOADS[args.workload]
     synthetic = args.workload == "synthetic"
-    sched = {"wavefront": {"wavefront": True}, "tree": {"tree": True}}.get(args.schedule, {})
+    W, H = wl["res"]
+    depth, spp = wl["depth"], wl["spp"]
+    sched = {"wavefront": {"wavefront": True}, "tree": {"tree": True}, "tile": {"tile": True}}.get(args.schedule, {})
     if synthetic:
         import tempfile
         from u_4a_2s_p3d_raytracer_template2_amd import synthetic as SY, api as API
         scene_file = None
         cam_file = os.path.join(tempfile.mkdtemp(prefix="p3d_bench_"), "camera.p3f")
-        cam = P.HostScene(SY.camera_p3f(cam_file, *RES)).camera()
-        t_b = time.time()
+        hs = P.HostScene(SY.camera_p3f(cam_file, W, H))
+        cam = hs.camera()
         desc, keep = API.make_desc(*SY.arrays(args.prims))
         make_handle = lambda: P.DeviceScene(desc, device=local_rank, keepalive=keep)
     else:
-        scene_file = scene_path("mount_low")
+        scene_file = scene_path(wl["scene"])
         hs = P.HostScene(scene_file)
-        hs.set_resolution(*RES)
+        hs.set_resolution(W, H)
         cam = hs.camera()
         make_handle = lambda: P.DeviceScene.from_host(hs, device=local_rank)
-    # The deeper tree levels of one 1080p frame are too few rays to fill 256 CUs (each level launch is
-    # bounded by single-wave latency), so consecutive frames -- independent work, exactly like the
-    # reference's render-another-image loop -- are overlapped on F streams, one scene handle each.
-    # With the frame tiled over N GPUs each rank holds 1/N of every frame, so it takes N times as many
-    # frames in flight to fill it.
+    B = args.frames_per_step if args.frames_per_step > 0 else wl["frames"]
+    # The deeper tree levels of one 1080p frame are too few rays to fill 256 CUs, so consecutive frames --
+    # independent work -- are overlapped on F streams, one scene handle each.  With the frame tiled over N GPUs
+    # each rank holds 1/N of every frame, so it takes N times as many frames in flight to fill it.
     F = args.frames_in_flight if args.frames_in_flight > 0 else 3 * world
-    F = max(1, min(F, args.frames_per_step))
+    F = max(1, min(F, B))
     main_stream = torch.cuda.current_stream()
     streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
     handles = []
@@ -270,54 +396,58 @@ def main():
         h.set_stream(st.cuda_stream)
         handles.append(h)
     ds = handles[0]
-    W, H = RES
-    B = args.frames_per_step
-    rows = H if world == 1 else MG.padded_rows(H, ROW_BLOCK, world)
+    rows = H if world == 1 else P.local_rows(H, ROW_BLOCK, world)
+    samples_dev = None
+    if spp:
+        smp = hs.samples(12345, spp)                       # the reference's libc rand() stream, seed of the survey
+        samples_dev = torch.from_numpy(smp).to(dev)        # uploaded ONCE (P3D_FLAG_DEVICE_SAMPLES)
+        del smp
+    kw = dict(max_depth=depth, accel=P.ACCEL_BVH, spp=spp, rank=rank, world=world, row_block=ROW_BLOCK,
+              samples_ptr=samples_dev.data_ptr() if spp else 0)
 
-    # HBM-resident outputs: B compact tile buffers per step (double use: gather source).  With the
-    # pipelined gather there are two sets: step i renders into set i % 2 while set (i - 1) % 2 is on the wire.
+    # HBM-resident outputs: B compact tile buffers per step (also the gather source); two sets when the gather
+    # of step i overlaps the rendering of step i + 1
     nbuf = 2 if (world > 1 and args.gather == "pipelined") else 1
     tile_sets = [torch.zeros((B, rows, W, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    tiles = tile_sets[0]
-    gathered_sets = frames = None
-    if world > 1 and rank == 0:
-        gathered_sets = [torch.zeros((world, B, rows, W, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-        frames = torch.zeros((B, H, W, 3), dtype=torch.uint8, device=dev)
     tile_bytes = rows * W * 3
+    gathered_sets = frames = gh = comm_stream = None
+    if world > 1:
+        comm_stream = torch.cuda.Stream(device=dev)
+        gh = make_handle()                                  # the handle whose stream carries gather + de-interleave
+        gh.set_stream(comm_stream.cuda_stream)
+        if rank == 0:
+            gathered_sets = [torch.zeros((world, B, rows, W, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+            frames = torch.zeros((B, H, W, 3), dtype=torch.uint8, device=dev)
 
     # work counters of this rank's share of one frame (counting build, same traversal)
-    ds.render_device(cam, rgb8_ptr=tiles[0].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
-                     rank=rank, world=world, row_block=ROW_BLOCK, **sched, counters=True)
+    ds.render_device(cam, rgb8_ptr=tile_sets[0][0].data_ptr(), counters=True, **sched, **kw)
     ctr = ds.counters()
     my_rays = ctr["rays"]
-    px_local = ctr["pixels"]
-    alg_bytes = ctr["algorithmic_bytes"] + 3 * px_local          # + rgb8 written per pixel
+    alg_bytes = ctr["algorithmic_bytes"] + 3 * ctr["pixels"]          # + rgb8 written per pixel
 
-    def render_frames(lead, buf=0):
+    def render_frames(lead, buf):
         """The B frames of a step into tile set `buf`: fork the side streams off `lead`, enqueue, join back."""
         for k in range(1, F):
             streams[k].wait_stream(lead)
         for f in range(B):
-            handles[f % F].render_device(cam, rgb8_ptr=tile_sets[buf][f].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
-                                         rank=rank, world=world, row_block=ROW_BLOCK, **sched)
+            handles[f % F].render_device(cam, rgb8_ptr=tile_sets[buf][f].data_ptr(), **sched, **kw)
         for k in range(1, F):
             lead.wait_stream(streams[k])
 
-    # A step is ~8 launches per frame; at a fraction of a millisecond per step the host's launch rate
-    # matters, most of all when N GPUs each hold 1/N of the work.  The frames of a step are captured once
-    # into a HIP graph (after an eager step has sized every workspace) and replayed with one launch.
+    # let every handle settle its schedule ALONE: for scenes read from HBM the library times every schedule on the
+    # first frames of a configuration, and frames running next to them on other streams would falsify the timing
+    for h in handles:
+        for _ in range(8):
+            h.render_device(cam, rgb8_ptr=tile_sets[0][0].data_ptr(), **sched, **kw)
+        h.sync()
+    torch.cuda.synchronize()
     graphs = None
-    # On one GPU the step is GPU-bound and eager launches measured marginally faster (42.6 vs 40.8 Grays/s),
-    # so "auto" captures only when the frame is tiled over several GPUs.
     want_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
-    if want_graph and not (synthetic and args.schedule == "default"):     # the schedule pick reads events: eager only
+    if want_graph:
         try:
-            render_frames(main_stream)
-            torch.cuda.synchronize()
             captured = []
             for buf in range(nbuf):
                 g = torch.cuda.CUDAGraph()
-                # thread_local: RCCL's watchdog thread may query events while this thread captures
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     lead = torch.cuda.current_stream()
                     handles[0].set_stream(lead.cuda_stream)
@@ -334,48 +464,41 @@ def main():
             if rank == 0:
                 print("bench.py: HIP graph capture unavailable (%s); launching eagerly" % exc, file=sys.stderr)
 
-    state = {"next": 0, "pending": None}
-
-    def finish(pending):
-        """Second half of a step: wait for its gather, restore the frames' row order on rank 0."""
-        work, buf, host_gathered = pending
-        work.wait()                                     # RCCL: the current stream waits, the host does not
-        if rank == 0:
-            if host_gathered is not None:
-                gathered_sets[buf].copy_(host_gathered)
-            ds.deinterleave_frames(gathered_sets[buf].data_ptr(), frames.data_ptr(), W, H, ROW_BLOCK, world, 3, B,
-                                   rank_stride_bytes=B * tile_bytes, tile_stride_bytes=tile_bytes)   # one launch
+    state = {"next": 0}
+    free_ev = [None] * nbuf                               # recorded on the comm stream when a set's gather is done
 
     def step():
         buf = state["next"]
         state["next"] = (buf + 1) % nbuf
+        if free_ev[buf] is not None:
+            main_stream.wait_event(free_ev[buf])          # the set is still on the wire from two steps ago
         if graphs is not None:
             graphs[buf].replay()
         else:
             render_frames(main_stream, buf)
         if world > 1:
+            comm_stream.wait_stream(main_stream)
             if rehearsal:
                 torch.cuda.synchronize()
                 src = tile_sets[buf].cpu()
-                dst = torch.zeros((world,) + tuple(src.shape), dtype=torch.uint8) if rank == 0 else None
+                dst = list(torch.zeros((world,) + tuple(src.shape), dtype=torch.uint8).unbind(0)) if rank == 0 else None
+                dist.gather(src, gather_list=dst, dst=0)
+                if rank == 0:
+                    with torch.cuda.stream(comm_stream):
+                        gathered_sets[buf].copy_(torch.stack(dst))
             else:
-                src, dst = tile_sets[buf], (gathered_sets[buf] if rank == 0 else None)
-            work = MG.gather_to_root(src, dist, rank, world, dst, async_op=True)
-            this = (work, buf, dst if rehearsal else None)
-            if nbuf == 1:
-                finish(this)
-            else:                                       # the previous step's gather had a whole render to complete
-                if state["pending"] is not None:
-                    finish(state["pending"])
-                state["pending"] = this
+                comm.gather(gh, tile_sets[buf].data_ptr(), gathered_sets[buf].data_ptr() if rank == 0 else 0, B * tile_bytes)
+            if rank == 0:                                 # one launch restores the row order of all B frames
+                gh.deinterleave_frames(gathered_sets[buf].data_ptr(), frames.data_ptr(), W, H, ROW_BLOCK, world, 3, B,
+                                       rank_stride_bytes=B * tile_bytes, tile_stride_bytes=tile_bytes)
+            ev = torch.cuda.Event()
+            ev.record(comm_stream)
+            free_ev[buf] = ev
 
     def barrier():
-        if state["pending"] is not None:
-            finish(state["pending"])
-            state["pending"] = None
+        torch.cuda.synchronize()                          # all streams of this rank, the comm stream included
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -386,27 +509,19 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    # roofline pass: HIP events on the launch stream around each frame and around its dominant
-    # kernel (wf_primary_kernel), averaged over steps*B frames
-    nl = max(args.steps, 1) * B
+    # single-frame latency (one frame in flight) and the dominant kernel's duration: HIP events on the launch stream
+    nl = max(min(args.steps * B, 200), 8)
     frame_ms_sum = kern_ms_sum = 0.0
     for _ in range(nl):
-        ds.render_device(cam, rgb8_ptr=tiles[0].data_ptr(), max_depth=MAX_DEPTH, accel=P.ACCEL_BVH,
-                         rank=rank, world=world, row_block=ROW_BLOCK, **sched, profile=True)
+        ds.render_device(cam, rgb8_ptr=tile_sets[0][0].data_ptr(), profile=True, **sched, **kw)
         f_ms, k_ms = ds.profile()
         frame_ms_sum += f_ms
         kern_ms_sum += k_ms
-    kern_ms = kern_ms_sum / nl
-    frame_dev_ms = frame_ms_sum / nl
-    # level-1 work of this rank's rows = a depth-1 frame (primary closest hits + their shadow queries)
-    ds.render_device(cam, rgb8_ptr=tiles[0].data_ptr(), max_depth=1, accel=P.ACCEL_BVH,
-                     rank=rank, world=world, row_block=ROW_BLOCK, **sched, counters=True)
-    c1 = ds.counters()
-    alg_bytes_l1 = c1["algorithmic_bytes"] + 3 * c1["pixels"]
+    frame_dev_ms, kern_ms = frame_ms_sum / nl, kern_ms_sum / nl
+    chosen = ds.last_schedule()
 
-    red_dev = torch.device("cpu") if rehearsal else dev
-    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-    rr = torch.tensor([float(my_rays)], dtype=torch.float64, device=red_dev)
+    tt = torch.tensor([dt], dtype=torch.float64)
+    rr = torch.tensor([float(my_rays)], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
@@ -414,65 +529,47 @@ def main():
     rays_frame = float(rr.item())
 
     if rank == 0:
-        # the frame that was timed (all ranks' tiles stitched on rank 0 when N > 1)
-        final = (frames[B - 1] if world > 1 else tiles[B - 1][:H]).cpu().numpy()
+        final = (frames[B - 1] if world > 1 else tile_sets[(state["next"] - 1) % nbuf][B - 1][:H]).cpu().numpy()
         total_rays = rays_frame * B * args.steps
-        achieved = alg_bytes_l1 / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        stats = ds.stats()
-        dominant = "whitted_tree_kernel" if ds.last_schedule() == "tree" else "wf_primary_kernel"
-        pmc_file = args.pmc_json or os.path.join(REPO, "profiles", "r01_synthetic_%d_pmc.json" % args.prims if synthetic
-                                                 else "r01_final_pmc.json")
-        try:
-            prof = json.load(open(pmc_file))
-            for name, e in prof["kernels"].items():       # the timed build: first template argument (COUNT) false
-                if dominant in name and "<true" not in name and "hbm_bytes_per_launch_corrected" in e:
-                    traffic = e["hbm_bytes_per_launch_corrected"]
-        except Exception:
-            pass
+        dominant = {"tree": "p3d::whitted_tree_kernel", "tile": "p3d::wf_tile_kernel", "wavefront": "p3d::wf_primary_kernel"}[chosen]
+        live = {"kernel": dominant, "kernel_ms": kern_ms, "frame_ms": frame_dev_ms, "alg_bytes": int(alg_bytes),
+                "alg_gbps": alg_bytes / (frame_dev_ms * 1e-3) / 1e9}
         line = {
-            "metric": "Mrays/s + ms/frame @1920x1080 depth4",
+            "metric": "Mrays/s + ms/frame @%dx%d depth%d" % (W, H, depth),
             "value": total_rays / dt_max / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "ms_per_frame": dt_max / args.steps / B * 1e3,
+            "ms_per_frame_latency": frame_dev_ms,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": ("synthetic: %d random spheres+triangles (SURVEY 8d scaling scene, seed 2024), mount_low camera" % args.prims)
                     if synthetic else
-                    "synthetic: P3D_Scenes/mount_low.p3f (12 primitives, 1 light) resolution/accel overridden to the config",
-            "config": {"workload": ("SURVEY 8d scaling scene, %d primitives, 1920x1080 depth 4 BVH" % args.prims) if synthetic
-                       else "mount_low.p3f 1920x1080 depth 4 BVH (BASELINE config 2)",
+                    "P3D_Scenes/%s.p3f, the reference's own scene asset (12 primitives, 1 light); resolution / accel / depth%s "
+                    "overridden to the configuration" % (wl["scene"], " / spp (host libc rand() sample stream, seed 12345)" if spp else ""),
+            "config": {"workload": ("SURVEY 8d scaling scene, %d primitives, 1920x1080 depth 4 BVH" % args.prims) if synthetic else wl["name"],
                        "frames_per_step": B, "frames_in_flight": F, "hip_graph": graphs is not None,
-                       "gather": ("pipelined" if nbuf == 2 else "after each step") if world > 1 else None,
+                       "schedule": chosen + (" (forced)" if sched else " (measured pick)"),
+                       "gather": None if world == 1 else ("p3d_gather over RCCL on a communication stream, %s"
+                                                          % ("two buffer sets (overlaps the next step)" if nbuf == 2 else "one buffer set")),
                        "rays_per_frame": int(rays_frame),
                        "row_block": ROW_BLOCK,
-                       "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved 16-row blocks + RCCL gather to rank 0" % world,
+                       "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved 16-row blocks + one RCCL gather to rank 0 through the C-ABI" % world,
                        "frame_checksum": int(final.astype(np.uint64).sum())},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": dominant, "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": int(alg_bytes_l1),
-                         "frame_device_ms": frame_dev_ms,
-                         "frame_algorithmic_bytes": int(alg_bytes),
-                         "frame_algorithmic_GBps": alg_bytes / (frame_dev_ms * 1e-3) / 1e9,
-                         "note": ("algorithmic bytes = 32 B/slab test + 16/48/32 B per sphere/triangle/box test + 3 B/px "
-                                  "(SURVEY 8d); scene read from HBM/L2 (%d MB on the device); `traffic` = PMC FETCH_SIZE x2 + "
-                                  "WRITE_SIZE per launch from %s" % (stats["device_bytes"] >> 20, os.path.basename(pmc_file)))
-                                 if synthetic else
-                                 "algorithmic bytes = 32 B/slab test + 16/48/32 B per sphere/triangle/box test + 3 B/px "
-                                 "(SURVEY 8d). The 12-primitive scene is LDS-resident: `traffic` (PMC FETCH_SIZE x2 + "
-                                 "WRITE_SIZE per launch, profiles/r01_final_pmc.json, 1-GPU whole-frame launch) is "
-                                 "frame buffer + ray/node queues, far below the algorithmic figure (see DESIGN.md)"},
+            "roofline": roofline_from_profiles(args.workload, live),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_synthetic(args.prims) if synthetic else cpu_baseline(scene_file)
+            line["cpu_baseline"] = cpu_baseline_synthetic(args.prims, depth) if synthetic else \
+                cpu_baseline(scene_file, wl.get("cpu_res", (W, H)), depth, spp)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+        gh.close()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
     for h in handles:
         h.close()

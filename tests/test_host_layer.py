@@ -73,6 +73,28 @@ def test_host_grid_is_the_reference_grid(name):
     assert np.array_equal(counts, c_o.astype(np.uint32))
 
 
+def test_host_triangle_normals_are_the_reference_normals():
+    """The device shades triangles with a normal the host computed once (csrc/scene_flatten.cpp) instead of
+    re-deriving it per hit: it must be, bit for bit, what the reference's getNormal(hit).normalize() returns --
+    the `normal` column of the known-answer table, which tests/golden/make_golden.py took from the reference's
+    own Triangle objects."""
+    with np.load(os.path.join(REPO, "tests", "golden", "kat.npz")) as z:
+        k = {n: z[n] for n in z.files}
+    sel = np.nonzero((k["type"] == O.TRIANGLE) & (k["hit"] == 1))[0]
+    assert len(sel) > 500
+    data = np.zeros((len(sel), 12), np.float32)
+    data[:, :9] = k["prim12"][sel, :9]
+    mats = np.zeros((1, 12), np.float32)
+    desc, keep = api.make_desc(np.full(len(sel), 1, np.uint32), data, np.zeros(len(sel), np.uint32), mats,
+                               np.zeros((0, 6), np.float32), (0, 0, 0))
+    L = P.lib()
+    L.p3dh_triangle_normals.restype = C.c_int64
+    L.p3dh_triangle_normals.argtypes = [C.POINTER(api.SceneDesc), C.c_void_p, C.c_uint64]
+    out = np.zeros((len(sel), 3), np.float32)
+    assert L.p3dh_triangle_normals(C.byref(desc), out.ctypes.data, len(sel)) == len(sel)
+    assert np.array_equal(out.view(np.uint32), k["normal"][sel].view(np.uint32))
+
+
 def test_missing_extension_fails_loudly(monkeypatch):
     monkeypatch.setattr(api, "_lib", None)
     monkeypatch.setattr(api, "LIB_PATH", "/nonexistent/libp3d_hip.so")

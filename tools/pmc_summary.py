@@ -47,7 +47,14 @@ def main():
                 launch[k] = {"grid": row["Grid_Size"], "wg": row["Workgroup_Size"], "lds": row["LDS_Block_Size"],
                              "vgpr": row["VGPR_Count"], "accum_vgpr": row["Accum_VGPR_Count"], "sgpr": row["SGPR_Count"],
                              "scratch": row["Scratch_Size"]}
-    res = {"_note": note, "kernels": {}}
+    # digest of the kernel sources these counters were taken from (bench.py flags a profile of other kernels as stale)
+    import hashlib
+    hd = hashlib.sha256()
+    cs_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "u_4a_2s_p3d_raytracer_template2_amd", "csrc")
+    for f in sorted(os.listdir(cs_dir)):
+        if f.endswith((".hip", ".h")):
+            hd.update(open(os.path.join(cs_dir, f), "rb").read())
+    res = {"_note": note, "kernel_source_digest": hd.hexdigest()[:16], "kernels": {}}
     for k, cs in sorted(acc.items()):
         e = {c: v[0] / v[1] for c, v in sorted(cs.items())}
         e["_n"] = max(v[1] for v in cs.values())

@@ -83,6 +83,15 @@ void p3dh_bvh_dump(const p3dh_bvh* b, uint32_t* nodes16, uint32_t* refs) {
     memcpy(refs, b->refs.data(), b->refs.size() * sizeof(uint32_t));
 }
 
+// ---- the triangle normals the device shades with (computed on the host by flatten_scene), scene order of the
+// triangles; returns their number.  For the CPU-side parity test against the reference's known answers.
+int64_t p3dh_triangle_normals(const p3d_scene_desc* d, float* out3, uint64_t cap) {
+    p3d::FlatScene F;
+    if (!p3d::flatten_scene(*d, F).empty()) return -1;
+    for (size_t i = 0; i < F.tris.size() && i < cap; i++) memcpy(out3 + 3 * i, F.tris[i].n, 12);
+    return (int64_t)F.tris.size();
+}
+
 // ---- host-only grid build (the reference's Grid::Build layout, csrc/grid_builder.cpp), for tests without a GPU
 // dims[3]; counts: cells' populations (nx*ny*nz) or NULL; returns the number of cells, or -1
 int64_t p3dh_grid_build(const p3d_scene_desc* d, int32_t* dims, uint32_t* counts, uint64_t counts_cap) {

@@ -100,7 +100,7 @@ struct p3d_scene {
     hipStream_t own_stream = nullptr, stream = nullptr;
     DevBuf<uint32_t> blob;              // nodes | leaf refs | spheres | sphere meta | tris | boxes | materials
     uint32_t blob_quads = 0;
-    uint32_t off_nodes = 0, off_refs = 0, off_spheres = 0, off_sphere_meta = 0, off_tris = 0, off_boxes = 0, off_mats = 0;
+    uint32_t off_nodes = 0, off_leaves = 0, off_spheres = 0, off_sphere_meta = 0, off_tris = 0, off_boxes = 0, off_mats = 0;
     DevBuf<PlaneRec> planes;
     DevBuf<PrimMeta> plane_meta;
     DevBuf<LightRec> lights;
@@ -237,12 +237,23 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     // the device builder needs at least two leaves; tiny scenes are built on the host either way
     const bool device_build = opts && opts->builder == 1 && F.build_prims.size() >= 64;
     if (device_build) {
-        // sections of the right size, filled in by build_lbvh_device() once the blob is on the device
+        // built on the device into scratch buffers, read back: the leaves are typed and the primitive arrays put
+        // into leaf order on the host (type_leaves) before anything is uploaded for rendering
         nodes.assign((F.build_prims.size() + 1) / 2 - 1, NodePair());
         refs.assign(F.build_prims.size(), 0u);
+        NodePair* d_nodes = nullptr; uint32_t* d_refs = nullptr;
+        hipError_t be = hipMalloc((void**)&d_nodes, nodes.size() * sizeof(NodePair));
+        if (be == hipSuccess) be = hipMalloc((void**)&d_refs, refs.size() * sizeof(uint32_t));
+        if (be == hipSuccess) be = build_lbvh_device(F.build_prims, bo, d_nodes, d_refs, bs, nullptr);
+        if (be == hipSuccess) be = hipMemcpy(nodes.data(), d_nodes, nodes.size() * sizeof(NodePair), hipMemcpyDeviceToHost);
+        if (be == hipSuccess) be = hipMemcpy(refs.data(), d_refs, refs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        (void)hipFree(d_nodes); (void)hipFree(d_refs);
+        if (be != hipSuccess) return fail(P3D_ERR_HIP, std::string("device BVH build: ") + hipGetErrorString(be));
     } else {
         build_bvh(F.build_prims, bo, nodes, refs, bs);
     }
+    TypedLeaves TL;
+    type_leaves(nodes, refs, F, TL);
     std::vector<SphereRec>& spheres = F.spheres; std::vector<PrimMeta>& sphere_meta = F.sphere_meta;
     std::vector<TriRec>& tris = F.tris; std::vector<BoxRec>& boxes = F.boxes;
     std::vector<PlaneRec>& planes = F.planes; std::vector<PrimMeta>& plane_meta = F.plane_meta;
@@ -278,7 +289,7 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
             return off;
         };
         s->off_nodes = section(nodes.data(), nodes.size() * sizeof(NodePair));
-        s->off_refs = section(refs.data(), refs.size() * sizeof(uint32_t));
+        s->off_leaves = section(TL.leaves.data(), TL.leaves.size() * sizeof(LeafRec));
         s->off_spheres = section(spheres.data(), spheres.size() * sizeof(SphereRec));
         s->off_sphere_meta = section(sphere_meta.data(), sphere_meta.size() * sizeof(PrimMeta));
         s->off_tris = section(tris.data(), tris.size() * sizeof(TriRec));
@@ -287,17 +298,17 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
         s->blob_quads = (uint32_t)(blob.size() / 4);
         if ((e = s->blob.upload(blob)) != hipSuccess) return bail(e, "upload scene blob");
     }
-    if (device_build) {
-        NodePair* d_nodes = reinterpret_cast<NodePair*>(s->blob.p + (size_t)s->off_nodes * 4);
-        uint32_t* d_refs = s->blob.p + (size_t)s->off_refs * 4;
-        if ((e = build_lbvh_device(F.build_prims, bo, d_nodes, d_refs, bs, s->own_stream)) != hipSuccess)
-            return bail(e, "device BVH build");
-    }
     if ((e = s->planes.upload(planes)) != hipSuccess) return bail(e, "upload planes");
     if ((e = s->plane_meta.upload(plane_meta)) != hipSuccess) return bail(e, "upload plane meta");
     if ((e = s->lights.upload(lights)) != hipSuccess) return bail(e, "upload lights");
     s->host_lights = lights;
     grid_prims_from_desc(*d, s->grid_src);
+    for (GridPrim& g : s->grid_src) {             // references in the uploaded (leaf-order) numbering
+        const uint32_t kind = g.ref >> kRefKindShift, idx = g.ref & kRefIndexMask;
+        if (kind == 0u) g.ref = (0u << kRefKindShift) | TL.map_sph[idx];
+        else if (kind == 1u) g.ref = (1u << kRefKindShift) | TL.map_tri[idx];
+        else if (kind == 2u) g.ref = (2u << kRefKindShift) | TL.map_box[idx];
+    }
     if ((e = hipMalloc((void**)&s->d_counters, sizeof(DeviceCounters))) != hipSuccess) return bail(e, "alloc counters");
     if ((e = hipMemset(s->d_counters, 0, sizeof(DeviceCounters))) != hipSuccess) return bail(e, "clear counters");
     memcpy(s->bg, d->background, sizeof s->bg);
@@ -457,7 +468,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     LaunchParams P;
     memset(&P, 0, sizeof P);
     P.blob = s->blob.p; P.blob_quads = s->blob_quads;
-    P.off_nodes = s->off_nodes; P.off_refs = s->off_refs; P.off_spheres = s->off_spheres;
+    P.off_nodes = s->off_nodes; P.off_leaves = s->off_leaves; P.off_spheres = s->off_spheres;
     P.off_sphere_meta = s->off_sphere_meta; P.off_tris = s->off_tris; P.off_boxes = s->off_boxes; P.off_mats = s->off_mats;
     P.planes = s->planes.p; P.plane_meta = s->plane_meta.p; P.lights = s->lights.p;
     // small scenes are rendered from an LDS copy shared by the 4 waves of a 256-thread workgroup
@@ -596,7 +607,13 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     if (prm->flags & P3D_FLAG_TREE_KERNEL) sched = SCHED_TREE;
     else if (prm->flags & P3D_FLAG_WAVEFRONT) sched = SCHED_WAVEFRONT;
     else if (prm->flags & P3D_FLAG_TILE_KERNEL) sched = SCHED_TILE;
-    else {
+    else if (lds_scene) {
+        // scenes served from LDS: by rule (measured once, on BASELINE configs 2 and 4: a one-sample 1080p frame
+        // 0.136 ms wavefront / 0.22 tile / 0.22 tree; 4096^2 x 4 samples 5.4 / 5.1 / 11.1 -- with samples the tile
+        // schedule needs no per-sample planes and no summing launch).  A timing-based pick is not used here: these
+        // frames are short enough to be run several at a time on separate handles, which falsifies the timings.
+        sched = prm->spp > 0 ? SCHED_TILE : SCHED_WAVEFRONT;
+    } else {
         // No schedule wins everywhere (one 1080p frame of a 12-primitive scene: wavefront 0.14 ms, tile 0.22;
         // 4096^2 x 4 samples of it: tile 5.1, wavefront 5.4; the dragon: tree = tile 2.3, wavefront 3.6; 1e6
         // random primitives: wavefront 3.7, tile 6.1, tree 9.5), so the library MEASURES: the first frames of a

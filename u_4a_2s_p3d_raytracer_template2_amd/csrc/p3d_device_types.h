@@ -15,7 +15,8 @@ namespace p3d {
 
 // One BVH2 inner node = both children's boxes + both child references: 64 B, four
 // dwordx4 loads, two slab tests per visit (2 x 32 algorithmic bytes).
-// child >= 0: inner node index.  child < 0: leaf, ~child = (first_ref << 3) | (count - 1).
+// child >= 0: inner node index.  child < 0: leaf.  As the builders emit it: ~child = (first_ref << 3) | (count - 1)
+// into a reference list; as uploaded (after type_leaves): ~child = index of a LeafRec.
 // An absent child has NaN bounds (every slab comparison is false).
 struct NodePair {
     float   lo0[3]; float hi0x;
@@ -25,13 +26,19 @@ struct NodePair {
 };
 static_assert(sizeof(NodePair) == 64, "NodePair must be 64 bytes");
 
-// leaf reference: kind in the top 2 bits, index into that kind's array below
+// A leaf of the uploaded tree: three typed runs in primitive arrays stored in LEAF ORDER (scene_flatten.h:
+// type_leaves).  A node's child c < 0 is leaf ~c; leaf 0 is the empty leaf absent children point at.
+struct LeafRec { uint32_t tri_first, sph_first, box_first, counts; };         // counts: tris | spheres << 8 | boxes << 16
+static_assert(sizeof(LeafRec) == 16, "LeafRec must be one quad");
+
+// primitive reference: kind in the top 2 bits, index into that kind's array below
 constexpr uint32_t kRefKindShift = 30;
 constexpr uint32_t kRefIndexMask = (1u << kRefKindShift) - 1u;
 
 struct SphereRec { float cx, cy, cz, r; };                                   // 16 B
 struct TriRec { float p0[3]; uint32_t scene_id; float e1[3]; uint32_t material;
-                float e2[3]; uint32_t pad; };                                // 48 B
+                float e2[3]; uint32_t pad;                                    // 48 B: what an intersection test reads
+                float n[3]; uint32_t pad2; };                                 // +16 B: getNormal().normalize(), read when shading a hit
 struct BoxRec { float mn[3]; uint32_t scene_id; float mx[3]; uint32_t material; };   // 32 B
 struct PlaneRec { float nx, ny, nz, d; };                                    // 16 B
 struct PrimMeta { uint32_t scene_id, material; };   // spheres and planes keep ids out of line
@@ -61,12 +68,12 @@ constexpr uint32_t kFeatSoftJitter = 1u, kFeatFuzzy = 2u;                  // La
 
 // Everything a render launch needs, passed by value (lands in SGPRs / kernarg segment).
 struct LaunchParams {
-    // scene: one blob of 16-byte quads holding every per-lane-indexed array (nodes, leaf refs,
+    // scene: one blob of 16-byte quads holding every per-lane-indexed array (nodes, leaf records,
     // spheres, sphere meta, triangles, boxes, materials; section offsets in quads), so that a
     // small scene can be copied into LDS with one loop; wave-uniform arrays stay separate
     const void*        blob;
     uint32_t           blob_quads;
-    uint32_t           off_nodes, off_refs, off_spheres, off_sphere_meta, off_tris, off_boxes, off_mats;
+    uint32_t           off_nodes, off_leaves, off_spheres, off_sphere_meta, off_tris, off_boxes, off_mats;
     int32_t            wg_waves;          // waves per workgroup of this launch (1, or 4 with an LDS scene)
     const PlaneRec*    planes;
     const PrimMeta*    plane_meta;

@@ -193,7 +193,7 @@ template <> struct View<false> {
     typedef GlobalScene type;
     static __device__ __forceinline__ GlobalScene make(const LaunchParams& P) {
         GlobalScene g; g.q = reinterpret_cast<const float4*>(P.blob);
-        g.o = SceneOffsets{P.off_nodes, P.off_refs, P.off_spheres, P.off_sphere_meta, P.off_tris, P.off_boxes, P.off_mats};
+        g.o = SceneOffsets{P.off_nodes, P.off_leaves, P.off_spheres, P.off_sphere_meta, P.off_tris, P.off_boxes, P.off_mats};
         return g;
     }
     static __device__ __forceinline__ uint32_t scene_dwords(const LaunchParams&) { return 0; }
@@ -206,7 +206,7 @@ template <> struct View<true> {
         for (uint32_t i = threadIdx.x; i < P.blob_quads; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
         LdsScene l;
-        l.o = SceneOffsets{P.off_nodes, P.off_refs, P.off_spheres, P.off_sphere_meta, P.off_tris, P.off_boxes, P.off_mats};
+        l.o = SceneOffsets{P.off_nodes, P.off_leaves, P.off_spheres, P.off_sphere_meta, P.off_tris, P.off_boxes, P.off_mats};
         return l;
     }
     static __device__ __forceinline__ uint32_t scene_dwords(const LaunchParams& P) { return P.blob_quads * 4; }
@@ -735,7 +735,7 @@ __global__ void debug_intersect_kernel(uint32_t n, const uint32_t* type, const f
         V3 p0 = mk(d[0], d[1], d[2]), p1 = mk(d[3], d[4], d[5]), p2 = mk(d[6], d[7], d[8]);
         V3 e1 = sub(p1, p0), e2 = sub(p2, p0);
         h = hit_triangle(r, p0, e1, e2, tt);
-        if (h) {
+        if (h) {     // the host-side statement of this lives in scene_flatten.cpp; the probe keeps the device arithmetic
             V3 m = mk((e1.y * e2.z) - (e1.z * e2.y), (e1.z * e2.x) - (e1.x * e2.z), (e1.x * e2.y) - (e1.y * e2.x));
             nn = normalized(normalized(m));
         }

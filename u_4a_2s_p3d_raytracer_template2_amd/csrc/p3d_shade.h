@@ -19,12 +19,8 @@ __device__ __forceinline__ V3 prim_normal(const LaunchParams& P, const SV& sv, u
         V3 n = normalized(sub(point, mk(s.x, s.y, s.z)));
         return normalized(n);
     } else if (kind == 1u) {                                            // RT/scene.cpp:10-25,46-49
-        float4 a0, b, c;
-        sv_tri(sv, idx, a0, b, c);
-        V3 V = mk(b.x, b.y, b.z), W = mk(c.x, c.y, c.z);
-        V3 n = mk((V.y * W.z) - (V.z * W.y), (V.z * W.x) - (V.x * W.z), (V.x * W.y) - (V.y * W.x));
-        n = normalized(n);
-        return normalized(n);
+        const float4 n = sv_tri_normal(sv, idx);                        // normalised twice on the host (scene_flatten.cpp)
+        return mk(n.x, n.y, n.z);
     } else if (kind == 2u) {
         float4 a, b;
         sv_box(sv, idx, a, b);
@@ -79,7 +75,7 @@ __device__ __forceinline__ bool light_occluded(const LaunchParams& P, const SV& 
 }
 // Blinn-Phong term of one unoccluded light, RT/main.cpp:512-525
 __device__ __forceinline__ void light_term(V3 L, V3 lcol, V3& color, const Mtl& M, const Ray& ray, V3 normal) {
-    L = normalized(L);
+    L = normalized(L);        // (the same value light_occluded() formed for a bounded shadow ray: CSE'd when inlined)
     V3 H = normalized(add(L, mul(ray.d, -1.0f)));
     float VdotN = dot(H, normal);
     float d1 = dot(normal, L);

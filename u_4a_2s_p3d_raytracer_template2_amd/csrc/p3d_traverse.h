@@ -30,7 +30,7 @@ struct Hit {
 // clock of the vector L1 return path and same-address lanes broadcast).
 extern __shared__ __attribute__((aligned(16))) uint32_t p3d_lds[];
 
-struct SceneOffsets { uint32_t nodes, refs, spheres, sphere_meta, tris, boxes, mats; };
+struct SceneOffsets { uint32_t nodes, leaves, spheres, sphere_meta, tris, boxes, mats; };
 
 struct GlobalScene {
     const float4* q; SceneOffsets o;
@@ -56,14 +56,20 @@ template <class SV> __device__ __forceinline__ void sv_node(const SV& sv, int32_
     float4 t = sv.ld4(b + 3);
     q3 = make_int4(__float_as_int(t.x), __float_as_int(t.y), __float_as_int(t.z), __float_as_int(t.w));
 }
-template <class SV> __device__ __forceinline__ uint32_t sv_leaf_ref(const SV& sv, uint32_t i) { return sv.ld1(sv.o.refs, i); }
+// a leaf = three typed ranges into the primitive arrays, which the host stores in LEAF ORDER (LeafRec):
+// x = first triangle, y = first sphere, z = first box, w = counts (triangles | spheres << 8 | boxes << 16)
+template <class SV> __device__ __forceinline__ uint4 sv_leaf(const SV& sv, uint32_t leaf) {
+    const float4 t = sv.ld4(sv.o.leaves + leaf);
+    return make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w));
+}
 template <class SV> __device__ __forceinline__ float4 sv_sphere(const SV& sv, uint32_t i) { return sv.ld4(sv.o.spheres + i); }
 template <class SV> __device__ __forceinline__ PrimMeta sv_sphere_meta(const SV& sv, uint32_t i) {
     uint2 m = sv.ld2(sv.o.sphere_meta, i); PrimMeta r; r.scene_id = m.x; r.material = m.y; return r;
 }
 template <class SV> __device__ __forceinline__ void sv_tri(const SV& sv, uint32_t i, float4& a, float4& b, float4& c) {
-    uint32_t q = sv.o.tris + i * 3u; a = sv.ld4(q); b = sv.ld4(q + 1); c = sv.ld4(q + 2);
+    uint32_t q = sv.o.tris + i * 4u; a = sv.ld4(q); b = sv.ld4(q + 1); c = sv.ld4(q + 2);
 }
+template <class SV> __device__ __forceinline__ float4 sv_tri_normal(const SV& sv, uint32_t i) { return sv.ld4(sv.o.tris + i * 4u + 3u); }
 template <class SV> __device__ __forceinline__ void sv_box(const SV& sv, uint32_t i, float4& a, float4& b) {
     uint32_t q = sv.o.boxes + i * 2u; a = sv.ld4(q); b = sv.ld4(q + 1);
 }
@@ -135,22 +141,25 @@ template <class SV> struct StackOf;
 template <> struct StackOf<LdsScene> { typedef WideStack type; };
 template <> struct StackOf<GlobalScene> { typedef SlimStack type; };
 
-struct SlabRay { float ox, oy, oz, ix, iy, iz; };
+struct SlabRay { float kx, ky, kz, ix, iy, iz; };     // i = 1/d, k = -o/d: a plane's distance is fma(plane, i, k)
 
 __device__ __forceinline__ SlabRay make_slab(const Ray& r) {
     SlabRay s;
-    s.ox = r.o.x; s.oy = r.o.y; s.oz = r.o.z;
     // 1-ulp hardware reciprocals are enough here: the slab test only has to be conservative
     // (boxes are padded by >= 1e-3, far above a relative 1e-7), it never decides a hit
     s.ix = __builtin_amdgcn_rcpf(r.d.x); s.iy = __builtin_amdgcn_rcpf(r.d.y); s.iz = __builtin_amdgcn_rcpf(r.d.z);
+    s.kx = -r.o.x * s.ix; s.ky = -r.o.y * s.iy; s.kz = -r.o.z * s.iz;
     return s;
 }
-// conservative slab test against a padded box; returns entry distance in tn
+// conservative slab test against a padded box; returns entry distance in tn.  One fused multiply-add per plane
+// (this arithmetic is ours, not the reference's: it only has to be conservative).  A direction component of zero
+// makes i infinite and a distance NaN where (plane - o) * i would have been an infinity: fminf / fmaxf drop NaNs,
+// so that axis is then ignored -- a few more visits for axis-parallel rays, never a missed box.
 __device__ __forceinline__ bool slab(const SlabRay& s, float lx, float ly, float lz, float hx,
                                      float hy, float hz, float tlimit, float& tn) {
-    float ax = (lx - s.ox) * s.ix, bx = (hx - s.ox) * s.ix;
-    float ay = (ly - s.oy) * s.iy, by = (hy - s.oy) * s.iy;
-    float az = (lz - s.oz) * s.iz, bz = (hz - s.oz) * s.iz;
+    float ax = __builtin_fmaf(lx, s.ix, s.kx), bx = __builtin_fmaf(hx, s.ix, s.kx);
+    float ay = __builtin_fmaf(ly, s.iy, s.ky), by = __builtin_fmaf(hy, s.iy, s.ky);
+    float az = __builtin_fmaf(lz, s.iz, s.kz), bz = __builtin_fmaf(hz, s.iz, s.kz);
     float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     t1 = t1 * 1.0000005f + 1e-30f;
@@ -158,38 +167,45 @@ __device__ __forceinline__ bool slab(const SlabRay& s, float lx, float ly, float
     return (t0 <= t1) && (t1 >= 0.0f) && (t0 <= tlimit);
 }
 
+// "t < closest_t" in scene order == nearest, lowest scene index on ties
+__device__ __forceinline__ void take_closer(Hit& best, bool h, float t, uint32_t ref, uint32_t sid, uint32_t mat) {
+    if (h && (t < best.t || (t == best.t && sid < best.sid))) { best.t = t; best.ref = ref; best.sid = sid; best.mat = mat; }
+}
+
+// One leaf.  No per-primitive reference to fetch and no kind to dispatch on: the leaf record names a run of
+// triangles, a run of spheres and a run of boxes in arrays the host stored in leaf order, so a test is one
+// round trip to the primitive's record (the reference list cost a dependent load + a kind switch per primitive).
 template <bool COUNT, class SV>
 __device__ __forceinline__ void leaf_closest(const LaunchParams& P, const SV& sv, const Ray& r, int32_t leaf,
                                              Hit& best, Ctr& ctr) {
-    uint32_t code = ~(uint32_t)leaf;
-    uint32_t first = code >> 3, n = (code & 7u) + 1u;
-    for (uint32_t i = 0; i < n; i++) {
-        uint32_t ref = sv_leaf_ref(sv, first + i);
-        uint32_t kind = ref >> kRefKindShift, idx = ref & kRefIndexMask;
-        float t; bool h; uint32_t sid = 0, mat = 0;
-        if (kind == 1u) {
-            float4 a, b, c;
-            sv_tri(sv, idx, a, b, c);
-            if (COUNT) ctr.tri++;
-            h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
-            sid = __float_as_uint(a.w); mat = __float_as_uint(b.w);
-        } else if (kind == 0u) {
-            float4 s = sv_sphere(sv, idx);
-            if (COUNT) ctr.sph++;
-            h = hit_sphere(r, mk(s.x, s.y, s.z), s.w, t);
-            if (h && t <= best.t) { PrimMeta m = sv_sphere_meta(sv, idx); sid = m.scene_id; mat = m.material; }
-        } else {
-            float4 a, b;
-            sv_box(sv, idx, a, b);
-            V3 nn;
-            if (COUNT) ctr.aab++;
-            h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
-            sid = __float_as_uint(a.w); mat = __float_as_uint(b.w);
-        }
-        // "t < closest_t" in scene order == nearest, lowest scene index on ties
-        if (h && (t < best.t || (t == best.t && sid < best.sid))) {
-            best.t = t; best.ref = ref; best.sid = sid; best.mat = mat;
-        }
+    const uint4 L = sv_leaf(sv, ~(uint32_t)leaf);
+    const uint32_t nt = L.w & 0xFFu, ns = (L.w >> 8) & 0xFFu, nb = L.w >> 16;
+    _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < nt; i++) {
+        float4 a, b, c;
+        sv_tri(sv, L.x + i, a, b, c);
+        if (COUNT) ctr.tri++;
+        float t;
+        const bool h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
+        take_closer(best, h, t, (1u << kRefKindShift) | (L.x + i), __float_as_uint(a.w), __float_as_uint(b.w));
+    }
+    _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < ns; i++) {
+        const float4 sp = sv_sphere(sv, L.y + i);
+        const PrimMeta m = sv_sphere_meta(sv, L.y + i);
+        if (COUNT) ctr.sph++;
+        float t;
+        const bool h = hit_sphere(r, mk(sp.x, sp.y, sp.z), sp.w, t);
+        take_closer(best, h, t, (0u << kRefKindShift) | (L.y + i), m.scene_id, m.material);
+    }
+    _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < nb; i++) {
+        float4 a, b; V3 nn;
+        sv_box(sv, L.z + i, a, b);
+        if (COUNT) ctr.aab++;
+        float t;
+        const bool h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
+        take_closer(best, h, t, (2u << kRefKindShift) | (L.z + i), __float_as_uint(a.w), __float_as_uint(b.w));
     }
 }
 
@@ -243,30 +259,34 @@ __device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const SV& sv, 
 template <bool COUNT, class SV>
 __device__ __forceinline__ bool leaf_any(const LaunchParams& P, const SV& sv, const Ray& r, int32_t leaf, bool bounded,
                                          float tmax, Ctr& ctr) {
-    uint32_t code = ~(uint32_t)leaf;
-    uint32_t first = code >> 3, n = (code & 7u) + 1u;
+    const uint4 L = sv_leaf(sv, ~(uint32_t)leaf);
+    const uint32_t nt = L.w & 0xFFu, ns = (L.w >> 8) & 0xFFu, nb = L.w >> 16;
     bool occluded = false;
-    for (uint32_t i = 0; i < n; i++) {
-        uint32_t ref = sv_leaf_ref(sv, first + i);
-        uint32_t kind = ref >> kRefKindShift, idx = ref & kRefIndexMask;
-        float t; bool h;
-        if (kind == 1u) {
-            float4 a, b, c;
-            sv_tri(sv, idx, a, b, c);
-            if (COUNT) ctr.tri++;
-            h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
-        } else if (kind == 0u) {
-            float4 s = sv_sphere(sv, idx);
-            if (COUNT) ctr.sph++;
-            h = hit_sphere(r, mk(s.x, s.y, s.z), s.w, t);
-        } else {
-            float4 a, b;
-            sv_box(sv, idx, a, b);
-            V3 nn;
-            if (COUNT) ctr.aab++;
-            h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
-        }
-        if (h && (!bounded || t < tmax)) occluded = true;
+    _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < nt; i++) {
+        float4 a, b, c;
+        sv_tri(sv, L.x + i, a, b, c);
+        if (COUNT) ctr.tri++;
+        float t;
+        const bool h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
+        occluded = occluded | (h && (!bounded || t < tmax));
+    }
+    _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < ns; i++) {
+        const float4 sp = sv_sphere(sv, L.y + i);
+        if (COUNT) ctr.sph++;
+        float t;
+        const bool h = hit_sphere(r, mk(sp.x, sp.y, sp.z), sp.w, t);
+        occluded = occluded | (h && (!bounded || t < tmax));
+    }
+    _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < nb; i++) {
+        float4 a, b; V3 nn;
+        sv_box(sv, L.z + i, a, b);
+        if (COUNT) ctr.aab++;
+        float t;
+        const bool h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
+        occluded = occluded | (h && (!bounded || t < tmax));
     }
     return occluded;
 }
@@ -472,46 +492,43 @@ struct WaveStack {
 template <bool COUNT, class SV>
 __device__ __forceinline__ void leaf_closest_packet(const LaunchParams& P, const SV& sv, const Ray& r, bool live,
                                                     int32_t leaf, Hit& best, Ctr& ctr) {
-    const uint32_t code = ~(uint32_t)leaf;
-    const uint32_t first = code >> 3, n = (code & 7u) + 1u;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t ref = __builtin_amdgcn_readfirstlane(sv_leaf_ref(sv, first + i));
-        const uint32_t kind = ref >> kRefKindShift, idx = ref & kRefIndexMask;
-        if (kind == 1u) {
-            float4 a, b, c;
-            sv_tri(sv, idx, a, b, c);
-            if (live) {
-                float t;
-                if (COUNT) ctr.tri++;
-                bool h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
-                uint32_t sid = __float_as_uint(a.w);
-                if (h && (t < best.t || (t == best.t && sid < best.sid))) {
-                    best.t = t; best.ref = ref; best.sid = sid; best.mat = __float_as_uint(b.w);
-                }
-            }
-        } else if (kind == 0u) {
-            float4 s = sv_sphere(sv, idx);
-            PrimMeta m = sv_sphere_meta(sv, idx);
-            if (live) {
-                float t;
-                if (COUNT) ctr.sph++;
-                bool h = hit_sphere(r, mk(s.x, s.y, s.z), s.w, t);
-                if (h && (t < best.t || (t == best.t && m.scene_id < best.sid))) {
-                    best.t = t; best.ref = ref; best.sid = m.scene_id; best.mat = m.material;
-                }
-            }
-        } else {
-            float4 a, b;
-            sv_box(sv, idx, a, b);
-            if (live) {
-                float t; V3 nn;
-                if (COUNT) ctr.aab++;
-                bool h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
-                uint32_t sid = __float_as_uint(a.w);
-                if (h && (t < best.t || (t == best.t && sid < best.sid))) {
-                    best.t = t; best.ref = ref; best.sid = sid; best.mat = __float_as_uint(b.w);
-                }
-            }
+    // the leaf is wave-uniform: its record and its primitives are fetched once for the wave (same address in
+    // every lane: a broadcast LDS read or one cache line), the counts are scalar loop bounds
+    const uint4 Lv = sv_leaf(sv, ~(uint32_t)leaf);
+    const uint32_t tri0 = __builtin_amdgcn_readfirstlane(Lv.x), sph0 = __builtin_amdgcn_readfirstlane(Lv.y),
+                   box0 = __builtin_amdgcn_readfirstlane(Lv.z), cnt = __builtin_amdgcn_readfirstlane(Lv.w);
+    const uint32_t nt = cnt & 0xFFu, ns = (cnt >> 8) & 0xFFu, nb = cnt >> 16;
+    _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < nt; i++) {
+        float4 a, b, c;
+        sv_tri(sv, tri0 + i, a, b, c);
+        if (live) {
+            if (COUNT) ctr.tri++;
+            float t;
+            const bool h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
+            take_closer(best, h, t, (1u << kRefKindShift) | (tri0 + i), __float_as_uint(a.w), __float_as_uint(b.w));
+        }
+    }
+    _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < ns; i++) {
+        const float4 sp = sv_sphere(sv, sph0 + i);
+        const PrimMeta m = sv_sphere_meta(sv, sph0 + i);
+        if (live) {
+            if (COUNT) ctr.sph++;
+            float t;
+            const bool h = hit_sphere(r, mk(sp.x, sp.y, sp.z), sp.w, t);
+            take_closer(best, h, t, (0u << kRefKindShift) | (sph0 + i), m.scene_id, m.material);
+        }
+    }
+    _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < nb; i++) {
+        float4 a, b;
+        sv_box(sv, box0 + i, a, b);
+        if (live) {
+            if (COUNT) ctr.aab++;
+            float t; V3 nn;
+            const bool h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
+            take_closer(best, h, t, (2u << kRefKindShift) | (box0 + i), __float_as_uint(a.w), __float_as_uint(b.w));
         }
     }
 }
@@ -602,25 +619,41 @@ __device__ __forceinline__ bool any_hit_packet(const LaunchParams& P, const SV& 
             const uint64_t m = side ? m1 : m0;
             if (!(m && c < 0)) continue;
             const bool hl = (side ? h1 : h0) && !occ;
-            const uint32_t code = ~(uint32_t)c;
-            const uint32_t first = code >> 3, n = (code & 7u) + 1u;
-            for (uint32_t i = 0; i < n; i++) {
-                const uint32_t ref = __builtin_amdgcn_readfirstlane(sv_leaf_ref(sv, first + i));
-                const uint32_t kind = ref >> kRefKindShift, idx = ref & kRefIndexMask;
-                float t; bool h = false;
-                if (kind == 1u) {
-                    float4 a, b, cc;
-                    sv_tri(sv, idx, a, b, cc);
-                    if (hl && !occ) { if (COUNT) ctr.tri++; h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(cc.x, cc.y, cc.z), t); }
-                } else if (kind == 0u) {
-                    float4 sp4 = sv_sphere(sv, idx);
-                    if (hl && !occ) { if (COUNT) ctr.sph++; h = hit_sphere(r, mk(sp4.x, sp4.y, sp4.z), sp4.w, t); }
-                } else {
-                    float4 a, b; V3 nn;
-                    sv_box(sv, idx, a, b);
-                    if (hl && !occ) { if (COUNT) ctr.aab++; h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn); }
+            const uint4 Lv = sv_leaf(sv, ~(uint32_t)c);
+            const uint32_t tri0 = __builtin_amdgcn_readfirstlane(Lv.x), sph0 = __builtin_amdgcn_readfirstlane(Lv.y),
+                           box0 = __builtin_amdgcn_readfirstlane(Lv.z), cnt = __builtin_amdgcn_readfirstlane(Lv.w);
+            const uint32_t nt = cnt & 0xFFu, ns = (cnt >> 8) & 0xFFu, nb = cnt >> 16;
+            _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < nt; i++) {
+                float4 a, b, cc;
+                sv_tri(sv, tri0 + i, a, b, cc);
+                if (hl && !occ) {
+                    if (COUNT) ctr.tri++;
+                    float t;
+                    const bool h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(cc.x, cc.y, cc.z), t);
+                    occ = occ | (h && (!bounded || t < tmax));
                 }
-                if (h && (!bounded || t < tmax)) occ = true;
+            }
+            _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < ns; i++) {
+                const float4 sp4 = sv_sphere(sv, sph0 + i);
+                if (hl && !occ) {
+                    if (COUNT) ctr.sph++;
+                    float t;
+                    const bool h = hit_sphere(r, mk(sp4.x, sp4.y, sp4.z), sp4.w, t);
+                    occ = occ | (h && (!bounded || t < tmax));
+                }
+            }
+            _Pragma("clang loop vectorize(disable) unroll(disable)")
+    for (uint32_t i = 0; i < nb; i++) {
+                float4 a, b;
+                sv_box(sv, box0 + i, a, b);
+                if (hl && !occ) {
+                    if (COUNT) ctr.aab++;
+                    float t; V3 nn;
+                    const bool h = hit_aabox(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), t, nn);
+                    occ = occ | (h && (!bounded || t < tmax));
+                }
             }
         }
         if (m0 && c0 < 0) m0 = 0;

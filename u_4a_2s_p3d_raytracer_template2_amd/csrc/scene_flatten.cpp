@@ -44,7 +44,18 @@ std::string flatten_scene(const p3d_scene_desc& d, FlatScene& F) {
                 b.lo[a] = std::min(v[a], std::min(v[3 + a], v[6 + a]));
                 b.hi[a] = std::max(v[a], std::max(v[3 + a], v[6 + a]));
             }
-            t.scene_id = i; t.material = mat; t.pad = 0;
+            t.scene_id = i; t.material = mat; t.pad = 0; t.pad2 = 0;
+            {   // Triangle's stored normal (RT/scene.cpp:16-25: component formulas, then normalize()) as rayTracing()
+                // uses it: getNormal(point).normalize() (RT/main.cpp:587) -- normalised twice, in float, in this order.
+                // Same IEEE operations the device used to repeat for every hit (-ffp-contract=off on both sides).
+                const float* V = t.e1; const float* W = t.e2;
+                float n[3] = {(V[1] * W[2]) - (V[2] * W[1]), (V[2] * W[0]) - (V[0] * W[2]), (V[0] * W[1]) - (V[1] * W[0])};
+                for (int pass = 0; pass < 2; pass++) {
+                    const float l = 1.0f / std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);     // RT/vector.cpp:66-71
+                    n[0] *= l; n[1] *= l; n[2] *= l;
+                }
+                t.n[0] = n[0]; t.n[1] = n[1]; t.n[2] = n[2];
+            }
             b.ref = (1u << kRefKindShift) | (uint32_t)F.tris.size();
             F.tris.push_back(t);
             pad(b); F.build_prims.push_back(b);
@@ -82,6 +93,40 @@ std::string flatten_scene(const p3d_scene_desc& d, FlatScene& F) {
         F.lights[i] = LightRec{{l[0], l[1], l[2]}, 0.0f, {l[3], l[4], l[5]}, 0.0f};
     }
     return std::string();
+}
+
+void type_leaves(std::vector<NodePair>& nodes, const std::vector<uint32_t>& refs, FlatScene& F, TypedLeaves& T) {
+    const uint32_t kNone = 0xFFFFFFFFu;
+    T.leaves.clear();
+    T.leaves.push_back(LeafRec{0, 0, 0, 0});                      // leaf 0: empty
+    T.map_sph.assign(F.spheres.size(), kNone); T.map_tri.assign(F.tris.size(), kNone); T.map_box.assign(F.boxes.size(), kNone);
+    std::vector<SphereRec> sph; std::vector<PrimMeta> sph_meta; std::vector<TriRec> tri; std::vector<BoxRec> box;
+    sph.reserve(F.spheres.size()); sph_meta.reserve(F.spheres.size()); tri.reserve(F.tris.size()); box.reserve(F.boxes.size());
+    auto convert = [&](int32_t& child, float probe) {
+        if (child >= 0) return;
+        if (probe != probe) { child = ~0; return; }               // absent child (NaN box): the empty leaf
+        const uint32_t code = ~(uint32_t)child, first = code >> 3, n = (code & 7u) + 1u;
+        LeafRec L{(uint32_t)tri.size(), (uint32_t)sph.size(), (uint32_t)box.size(), 0};
+        uint32_t nt = 0, ns = 0, nb = 0;
+        for (uint32_t i = first; i < first + n && i < refs.size(); i++) {
+            const uint32_t kind = refs[i] >> kRefKindShift, idx = refs[i] & kRefIndexMask;
+            if (kind == 0u) { T.map_sph[idx] = (uint32_t)sph.size(); sph.push_back(F.spheres[idx]); sph_meta.push_back(F.sphere_meta[idx]); ns++; }
+            else if (kind == 1u) { T.map_tri[idx] = (uint32_t)tri.size(); tri.push_back(F.tris[idx]); nt++; }
+            else { T.map_box[idx] = (uint32_t)box.size(); box.push_back(F.boxes[idx]); nb++; }
+        }
+        L.counts = nt | (ns << 8) | (nb << 16);
+        child = ~(int32_t)T.leaves.size();
+        T.leaves.push_back(L);
+    };
+    for (NodePair& nd : nodes) { convert(nd.child0, nd.lo0[0]); convert(nd.child1, nd.lo1xy[0]); }
+    // primitives no leaf holds (left out of the tree by cull_never_hit) keep a place behind the others
+    for (size_t i = 0; i < F.spheres.size(); i++)
+        if (T.map_sph[i] == kNone) { T.map_sph[i] = (uint32_t)sph.size(); sph.push_back(F.spheres[i]); sph_meta.push_back(F.sphere_meta[i]); }
+    for (size_t i = 0; i < F.tris.size(); i++)
+        if (T.map_tri[i] == kNone) { T.map_tri[i] = (uint32_t)tri.size(); tri.push_back(F.tris[i]); }
+    for (size_t i = 0; i < F.boxes.size(); i++)
+        if (T.map_box[i] == kNone) { T.map_box[i] = (uint32_t)box.size(); box.push_back(F.boxes[i]); }
+    F.spheres.swap(sph); F.sphere_meta.swap(sph_meta); F.tris.swap(tri); F.boxes.swap(box);
 }
 
 }  // namespace p3d

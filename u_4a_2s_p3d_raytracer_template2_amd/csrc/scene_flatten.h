@@ -24,5 +24,16 @@ struct FlatScene {
 // returns an empty string on success, otherwise the reason the description is invalid
 std::string flatten_scene(const p3d_scene_desc& d, FlatScene& out);
 
+// The builders emit leaves as runs of a reference list (kind << 30 | index).  Walking that costs a dependent
+// load and a kind switch per primitive, so before upload the primitive arrays are PERMUTED INTO LEAF ORDER and
+// every leaf becomes a LeafRec of three typed runs; nodes' leaf children are rewritten to ~(leaf index), absent
+// children to leaf 0 (empty).  Records carry their scene id and material, so the order of the arrays is free.
+// map_*[old index] = new index (for whoever holds references in the old numbering: the uniform grid).
+struct TypedLeaves {
+    std::vector<LeafRec> leaves;
+    std::vector<uint32_t> map_sph, map_tri, map_box;
+};
+void type_leaves(std::vector<NodePair>& nodes, const std::vector<uint32_t>& refs, FlatScene& F, TypedLeaves& out);
+
 }  // namespace p3d
 #endif
