@@ -552,7 +552,7 @@ def main():
                     "overridden to the configuration" % (wl["scene"], " / spp (host libc rand() sample stream, seed 12345)" if spp else ""),
             "config": {"workload": ("SURVEY 8d scaling scene, %d primitives, 1920x1080 depth 4 BVH" % args.prims) if synthetic else wl["name"],
                        "frames_per_step": B, "frames_in_flight": F, "hip_graph": graphs is not None,
-                       "schedule": chosen + (" (forced)" if sched else " (measured pick)"),
+                       "schedule": chosen + (" (forced)" if sched else " (library default)"),
                        "gather": None if world == 1 else ("p3d_gather over RCCL on a communication stream, %s"
                                                           % ("two buffer sets (overlaps the next step)" if nbuf == 2 else "one buffer set")),
                        "rays_per_frame": int(rays_frame),

@@ -142,8 +142,11 @@ typedef struct p3d_render_params {
                                     layout): the caller uploaded the sample array once instead of per call    */
 #define P3D_FLAG_PROFILE 16u     /* bracket the frame and its dominant kernel (the level-1 /
                                     tree launch) with HIP events for p3d_get_profile()           */
-#define P3D_FLAG_NO_PACKET 8u    /* per-lane BVH walk even for trees small enough for the
-                                    wave-wide (packet) walk                                       */
+#define P3D_FLAG_NO_PACKET 8u    /* (kept for ABI compatibility: the per-lane BVH walk is the default now)           */
+#define P3D_FLAG_PACKET_WALK 256u /* wave-wide (packet) BVH walk for trees of up to 64 node pairs: node and primitive
+                                    records fetched once per wave, a node visited when any lane's slab test passes.
+                                    Same results as the default per-lane walk; measured slower since the leaves
+                                    became typed runs (0.137 vs 0.133 ms on BASELINE config 2)                       */
 #define P3D_FLAG_NO_LDS_SCENE 4u /* read the scene from HBM/L2 even when it would fit in LDS    */
 #define P3D_FLAG_TREE_KERNEL 2u  /* one launch, per-lane post-order frame stack in LDS, instead
                                     of the default level-by-level wavefront schedule; results are

@@ -31,7 +31,7 @@ def test_soft_shadow_grid_matches_oracle(name, accel, depth):
     ref = sc.render(max_depth=depth, accel=accel, spp=0, soft_shadow=True)
     plain = sc.render(max_depth=depth, accel=accel, spp=0)
     assert ref["counters"]["shadow_queries"] > 8 * plain["counters"]["shadow_queries"]      # 16 sub-lights per light
-    for kw in (dict(), dict(tree=True), dict(wavefront=True), dict(no_lds=True, no_packet=True)):
+    for kw in (dict(), dict(tree=True), dict(wavefront=True), dict(no_lds=True), dict(packet=True)):
         out = ds.render(hs.camera(), max_depth=depth, accel=accel, spp=0, soft_shadow=True, counters=True, **kw)
         assert np.array_equal(out["hit_id"], ref["hit_id"])
         assert np.abs(out["rgb32f"] - ref["rgb32f"]).max() <= 1e-4
@@ -85,7 +85,7 @@ def test_random_streams_are_reproducible_and_shard_independent():
     full = MG.stitch_reference(parts, RES[1], 16)
     assert np.array_equal(full, a["rgb32f"])
     # LDS-resident and HBM-resident scene paths draw the same numbers
-    d = ds.render(cam, no_lds=True, no_packet=True, **kw)
+    d = ds.render(cam, no_lds=True, **kw)
     assert np.array_equal(d["rgb32f"], a["rgb32f"])
     # ... and so do the tile schedule and the wavefront schedule
     for sched in ("tile", "wavefront"):

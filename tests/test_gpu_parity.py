@@ -17,7 +17,8 @@ import u_4a_2s_p3d_raytracer_template2_amd as P
 pytestmark = pytest.mark.gpu
 
 RGB_TOL = 1e-4          # per-channel float tolerance stated by north_star
-U8_MISMATCH_FRAC = 2e-4  # quantisation flips allowed (each at most 1 level), see DESIGN.md
+U8_MISMATCH_FRAC = 2e-5  # quantisation flips allowed (each at most 1 level): powf's last bit (ROCm vs glibc) is the only
+                         # known source; measured 0 on every frame so far.  2e-5 means none in a golden-sized frame.
 
 CASES = json.load(open(os.path.join(GOLDEN, "cases.json")))
 
@@ -126,9 +127,9 @@ def test_schedules_and_scene_placements_are_bit_identical():
     for name in ("c2_mount_low_256x144_d4_bvh", "c4_mount_low_96_d6_spp2", "balls_box_128_d4_bvh", "dof_64_d4_spp4",
                  "balls_medium_128_d4_none"):
         a = gpu_render(CASES[name], counters=True, wavefront=True)
-        for kw in (dict(tree=True), dict(no_lds=True), dict(tree=True, no_lds=True), dict(no_packet=True),
-                   dict(no_packet=True, no_lds=True), dict(tile=True), dict(tile=True, no_lds=True),
-                   dict(tile=True, no_packet=True), dict(tile=True, no_packet=True, no_lds=True), dict(wavefront=True, no_lds=True)):
+        for kw in (dict(tree=True), dict(no_lds=True), dict(tree=True, no_lds=True), dict(wavefront=True, packet=True),
+                   dict(wavefront=True, packet=True, no_lds=True), dict(tile=True), dict(tile=True, no_lds=True),
+                   dict(tile=True, packet=True), dict(tile=True, packet=True, no_lds=True), dict(wavefront=True, no_lds=True)):
             b = gpu_render(CASES[name], counters=True, **kw)
             assert np.array_equal(a["rgb8"], b["rgb8"]) and np.array_equal(a["hit_id"], b["hit_id"]), (name, kw)
             assert np.array_equal(a["rgb32f"].view(np.uint32), b["rgb32f"].view(np.uint32)), (name, kw)
@@ -167,6 +168,21 @@ def test_grid_mode_full_size_against_live_oracle():
         where = (ref["rgb8"] != bvh["rgb8"]).any(axis=2)
         assert np.array_equal(out["rgb8"][where], ref["rgb8"][where])
     print("grid mode: %d px differ from BVH mode, all reproduced" % n_diff)
+
+
+def test_config4_at_1024_against_live_oracle():
+    """BASELINE config 4's shape (mount_low, depth 6, 2x2 jittered samples + thin lens, seed 12345) at 1024x1024:
+    every pixel against the oracle's serial render (its libc rand() stream is consumed in pixel order, so one
+    thread: ~3 s), on the schedule the library picks (tile) and on the wavefront schedule.  The full 4096x4096
+    frame is tools/config4_parity.py (30 s of CPU)."""
+    m = dict(scene="mount_low", res=[1024, 1024], accel=2, spp=2, max_depth=6, seed=12345)
+    sc = O.Scene(scene_path("mount_low")); sc.set_resolution(1024, 1024)
+    ref = sc.render(max_depth=6, accel=2, spp=2, seed=12345)
+    for kw in (dict(), dict(wavefront=True)):
+        out = gpu_render(m, counters=True, **kw)
+        mx, frac = compare(out, ref["rgb8"], ref["rgb32f"], ref["hit_id"], "config4-1024")
+        assert out["counters"]["rays"] == ref["counters"]["rays"]
+    print("config4 @1024: max rgb diff %.3g, rgb8 mismatch fraction %.3g, %d rays" % (mx, frac, ref["counters"]["rays"]))
 
 
 def test_config2_full_size_against_live_oracle():

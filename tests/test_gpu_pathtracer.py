@@ -67,6 +67,33 @@ def test_accumulation_matches_the_shader_recurrence_and_sample_split_sums():
     pt.close()
 
 
+def test_full_size_properties_1920x1080():
+    """BASELINE config 5's frame size (1920x1080), 16 frames: size-independent properties of the accumulation --
+    alpha == frame count in every pixel, finite colours where the samples are finite, the 8-way sample split
+    (first_frame = rank, stride = world: what 8 GPUs trace) sums to the one-GPU linear image, a strip of the
+    image equals the same strip of the CPU restatement on the overwhelming majority of pixels."""
+    W, H, N = 1920, 1080, 16
+    pt = P.PathTracer()
+    rgba, lin = pt.render(W, H, N)
+    fin = np.isfinite(rgba).all(axis=2)
+    assert fin.mean() > 0.995
+    assert np.array_equal(rgba[..., 3][fin], np.full(int(fin.sum()), N, np.float32))
+    assert rgba[..., :3][fin].min() >= 0.0          # (the shader does not clamp bright samples: values above 1 occur)
+    total = np.zeros_like(lin)
+    for r in range(8):
+        total += pt.render(W, H, N // 8, first_frame=r, frame_stride=8)[1]
+    ok = np.isfinite(lin).all(axis=2) & np.isfinite(total).all(axis=2)
+    assert np.allclose(total[ok], lin[ok], rtol=1e-4, atol=1e-4)
+    # one frame of a 1920x24 strip against the oracle (same pixel coordinates: the strip is rows 528..551)
+    one, lin1 = pt.render(W, H, 1)
+    ref_rgba, ref_lin = O.pt_render(W, H, 1, threads=8)
+    rows = slice(528, 552)
+    d = np.abs(lin1[rows] - ref_lin[rows]).max(axis=2)
+    okr = np.isfinite(d)
+    assert np.median(d[okr]) < 1e-5 and (d[okr] > 1e-3).mean() < 0.01
+    pt.close()
+
+
 def test_errors():
     pt = P.PathTracer()
     with pytest.raises(P.P3DError):

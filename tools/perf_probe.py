@@ -58,7 +58,7 @@ for sched in (["tile", "wavefront", "tree"] if not a.tree else ["tree"]):
    for occ in [int(v) for v in a.occ.split(",")]:
     for ch in [int(v) for v in a.chunks.split(",")]:
         ds.set_tuning(xcd_chunk=ch, waves_per_simd=occ)
-        kw = dict(max_depth=a.depth, accel=a.accel, no_lds=no_lds, no_packet=no_packet, **{sched: True})
+        kw = dict(max_depth=a.depth, accel=a.accel, no_lds=no_lds, packet=not no_packet, **{sched: True})
         for _ in range(5):
             ds.render_device(cam, rgb8_ptr=buf.data_ptr(), **kw)
         ds.timer_begin()

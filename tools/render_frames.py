@@ -22,7 +22,7 @@ else:
     ds, cam = P.DeviceScene.from_host(hs), hs.camera()
 buf = torch.zeros((res[1] + 16, res[0], 3), dtype=torch.uint8, device="cuda")
 kw = {"wavefront": dict(wavefront=True), "tree": dict(tree=True), "tile": dict(tile=True), "default": {},
-      "wavefront_lane": dict(wavefront=True, no_packet=True)}[sched]
+      "wavefront_packet": dict(wavefront=True, packet=True)}[sched]
 for _ in range(n):
     ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=depth, **kw)
 ds.sync()

@@ -141,9 +141,14 @@ struct p3d_scene {
     struct { uint32_t key = 0xFFFFFFFFu; uint32_t stack = 0; unsigned waves = 0, primary_waves = 0; } wf_occ;                 // ... of the deeper-level kernel
     hipStream_t lane_stream[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
-    // worst-case queues a frame may allocate; only what a frame needs is ever allocated.  64 GiB holds
-    // BASELINE config 4 (4096^2, depth 6: 58 GB worst case) in one band: 10.7 -> 9.3 ms against 8 GiB.
+    // upper limit of the workspace one frame may allocate (wavefront schedule: worst-case level queues of a band
+    // of tile rows; tile schedule: one slot per resident workgroup).  64 GiB holds BASELINE config 4's wavefront
+    // queues (4096^2, depth 6: 58 GB worst case) in one band: 10.7 -> 9.3 ms against 8 GiB.
     size_t workspace_budget = (size_t)64 << 30;
+    // what of that budget this device can actually give: re-read (hipMemGetInfo) whenever the budget or the frame
+    // configuration changes, so that several scene handles, or a framework holding most of the HBM, shrink the
+    // bands / fall back to another schedule instead of failing in hipMalloc
+    size_t budget_avail = 0; int32_t budget_key[4] = {0, 0, 0, -1};
     DeviceCounters* d_counters = nullptr;
     bool counters_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -366,7 +371,7 @@ int p3d_set_tuning(p3d_scene* s, int32_t xcd_chunk, int32_t workspace_mib, int32
     if (workspace_mib < 0) return fail(P3D_ERR_ARG, "workspace_mib must be >= 0");
     s->pick.key[0] = 0;                                                // tuning changes what the schedules cost: measure again
     if (xcd_chunk) s->xcd_chunk = xcd_chunk;
-    if (workspace_mib) s->workspace_budget = (size_t)workspace_mib << 20;
+    if (workspace_mib) { s->workspace_budget = (size_t)workspace_mib << 20; s->budget_key[0] = 0; }
     if (waves_per_simd >= 0) {
         if (waves_per_simd != 0 && waves_per_simd != 5 && waves_per_simd != 6)
             return fail(P3D_ERR_ARG, "waves_per_simd must be 0 (default), 5 or 6");
@@ -476,7 +481,10 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     P.wg_waves = lds_scene ? 4 : 1;
     // small trees are walked by the whole wave together (packet walk), large ones per lane; GRID mode walks the
     // reference's uniform grid per lane
-    const bool packet = prm->accel != P3D_ACCEL_GRID && !(prm->flags & P3D_FLAG_NO_PACKET) && s->stats.n_nodes <= s->packet_node_limit;
+    // (the per-lane walk is the default everywhere: with typed leaves it is the faster one on BASELINE config 2 too,
+    //  0.133 vs 0.137 ms; P3D_FLAG_PACKET_WALK asks for the wave-wide walk, which exists for trees up to 64 node pairs)
+    const bool packet = prm->accel != P3D_ACCEL_GRID && (prm->flags & P3D_FLAG_PACKET_WALK) && !(prm->flags & P3D_FLAG_NO_PACKET) &&
+                        s->stats.n_nodes <= s->packet_node_limit;
     const int walk = prm->accel == P3D_ACCEL_GRID ? 2 : (packet ? 1 : 0);
     if (prm->accel == P3D_ACCEL_GRID) {
         if (s->unit_rays_only) return fail(P3D_ERR_STATE, "scene was built with cull_never_hit: GRID mode walks the reference's grid over ALL primitives; use accel BVH");
@@ -568,6 +576,19 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     if (stochastic && (prm->flags & P3D_FLAG_TREE_KERNEL))
         return fail(P3D_ERR_ARG, "features with random draws need the tile or the wavefront schedule");
 
+    {   // the workspace budget, capped by what the device has free (+ what this handle already holds)
+        const int32_t bkey[4] = {cam->res_x, cam->res_y, prm->max_depth, prm->spp};
+        if (memcmp(bkey, s->budget_key, sizeof bkey) != 0) {
+            size_t free_b = 0, total_b = 0;
+            size_t held = s->tile_ws.cap + s->wf_planes.cap;
+            for (auto& w : s->ws) { for (auto& b : w.rays) held += b.cap; for (auto& b : w.nodes) held += b.cap; for (auto& b : w.rng) held += b.cap; }
+            s->budget_avail = s->workspace_budget;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                s->budget_avail = std::min<size_t>(s->workspace_budget, (size_t)((double)(free_b + held) * 0.85));
+            memcpy(s->budget_key, bkey, sizeof bkey);
+        }
+    }
+    const size_t budget = s->budget_avail;
     // what the tile schedule needs: its LDS, and one private workspace slot per resident workgroup
     LaunchParams PT = P;                                   // tile geometry: 16x16 tiles, 4 waves per workgroup
     PT.wg_waves = 4;
@@ -587,7 +608,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         }
         tile_blocks = s->tile_occ.blocks;
         tile_blocks = std::min(tile_blocks, PT.n_tiles);
-        tile_blocks = (int)std::min<size_t>((size_t)tile_blocks, s->workspace_budget / slot_bytes);
+        tile_blocks = (int)std::min<size_t>((size_t)tile_blocks, budget / slot_bytes);
         // fewer resident workgroups than a quarter of the CUs: the per-tile worst case of this depth does not fit
         tile_ok = tile_blocks >= std::min(64, PT.n_tiles);
     }
@@ -597,7 +618,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     const int lanes = prm->spp > 0 ? std::min(kLanes, prm->spp * prm->spp) : 1;
     size_t wf_bpp = wavefront_bytes_per_pixel(prm->max_depth);
     if (stochastic) for (int l = 2; l <= prm->max_depth; l++) wf_bpp += ((size_t)1 << (l - 1)) * sizeof(uint32_t);
-    size_t band_tile_rows = wf_bpp ? s->workspace_budget / lanes / (wf_bpp * tile_row_px) : (size_t)P.tiles_y;
+    size_t band_tile_rows = wf_bpp ? budget / lanes / (wf_bpp * tile_row_px) : (size_t)P.tiles_y;
     if (wf_bpp == 0) band_tile_rows = (size_t)P.tiles_y;
     band_tile_rows = std::min<size_t>(band_tile_rows, (size_t)P.tiles_y);
     const bool wavefront_ok = band_tile_rows > 0;
