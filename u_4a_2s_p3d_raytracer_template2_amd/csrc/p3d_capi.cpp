@@ -59,8 +59,11 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU
 constexpr int kMaxDepth = 16;
+#ifndef P3D_HBM_STACK_DWORDS
+#define P3D_HBM_STACK_DWORDS 64u      // per entry per wave: RefStack 64 (4-byte entries; p3d_traverse.h), SlimStack 96
+#endif
+constexpr uint32_t kHbmStackDwordsPerEntry = P3D_HBM_STACK_DWORDS;
 constexpr int kLanes = 4;                             // concurrent sample passes of one frame
-constexpr unsigned kPersistentWaves = 256 * 16;       // deeper-level launches of LDS-resident scenes (full waves)
 constexpr unsigned kPersistentWavesNarrow = 256 * 16 * 4;   // ... of HBM-resident scenes (narrow waves, 4 per SIMD)
 
 template <typename T>
@@ -399,13 +402,16 @@ constexpr int kShards = 64;   // queue shards; spreads the slot-allocation atomi
 int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t stream, LaunchParams P, bool count, bool lds,
                        int walk, size_t shard_px, bool profile) {
     const int D = P.max_depth;
+    // scenes read from HBM wait on fetches most of the time: a register budget of 6 waves per SIMD measured 3 %
+    // faster than the compiler's default there (10^6 primitives 3.19 -> 3.08 ms); LDS scenes keep the default
+    const int occ = s->occupancy ? s->occupancy : (lds ? 0 : 6);
     const size_t n_counts = (size_t)2 * (kMaxDepth + 2) * kShards;
     uint32_t* counts = (uint32_t*)ws.counts.p;                              // [level][shard] ray counts, then node counts
-    // cleared on the stream in front of every pass: nothing about a frame lives in host state, so a captured
-    // frame can be replayed any number of times (a kernel, not hipMemsetAsync: a captured memset node of this
-    // buffer faulted on replay under ROCm 7.2 -- "write access to a read-only page")
-    HIP_TRY(launch_clear_words(counts, (uint32_t)n_counts, stream));
-    P.wf_clear = nullptr; P.wf_clear_words = 0;
+    // No clearing launch and nothing about a frame in host state (a captured frame can be replayed any number of
+    // times): the level-1 launch zeroes what the previous pass left, under a device-side parity -- see
+    // LaunchParams::wf_alt.  The buffer is zeroed once, when it is allocated.
+    P.wf_clear = counts; P.wf_clear_words = (uint32_t)n_counts;
+    P.wf_alt = counts + n_counts; P.wf_ctrl = counts + n_counts + 4 * kShards;
     auto rays = [&](int l) { return (l >= 2 && l <= D) ? (RayRec*)ws.rays[l].p : nullptr; };
     auto nodes = [&](int l) { return (l >= 1 && l <= D - 1) ? (NodeRec*)ws.nodes[l].p : nullptr; };
     auto qcount = [&](int l) { return counts + (size_t)l * kShards; };
@@ -420,15 +426,15 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
     P.wf_nodes_parent = nullptr; P.wf_ncap_parent = 0;
     P.wf_nodes_self = nodes(1); P.wf_ncount_self = ncount(1); P.wf_ncap_self = cap(1);
     {   // persistent grids: as many waves as can be resident (cached occupancy queries)
-        const uint32_t okey = (count ? 1u : 0u) | (lds ? 2u : 0u) | ((uint32_t)walk << 2) | (P.features ? 16u : 0u) | ((uint32_t)s->occupancy << 5);
+        const uint32_t okey = (count ? 1u : 0u) | (lds ? 2u : 0u) | ((uint32_t)walk << 2) | (P.features ? 16u : 0u) | ((uint32_t)occ << 5);
         if (s->wf_occ.key != okey || s->wf_occ.stack != P.trav_stack_dwords) {
-            HIP_TRY(wf_resident_waves(P, false, count, lds, walk, s->occupancy, &s->wf_occ.waves));
+            HIP_TRY(wf_resident_waves(P, false, count, lds, walk, occ, &s->wf_occ.waves));
             s->wf_occ.key = okey; s->wf_occ.stack = P.trav_stack_dwords;
         }
     }
     const unsigned resident_waves = s->wf_occ.waves;
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], stream));
-    HIP_TRY(launch_wf_primary(P, count, lds, walk, s->occupancy, stream));
+    HIP_TRY(launch_wf_primary(P, count, lds, walk, occ, stream));
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], stream));
     for (int l = 2; l <= D; l++) {
         P.wf_level = l;
@@ -441,7 +447,7 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
         // LDS scenes: as many waves as can be resident (the kernel numbers its batches through all shards)
         unsigned waves = (unsigned)std::min<size_t>((total + 63) / 64, lds ? resident_waves : kPersistentWavesNarrow);
         waves = std::max<unsigned>(kShards * 4, (waves / (kShards * 4)) * (kShards * 4));   // whole workgroups per shard
-        HIP_TRY(launch_wf_secondary(P, count, lds, walk, s->occupancy, waves, stream));
+        HIP_TRY(launch_wf_secondary(P, count, lds, walk, occ, waves, stream));
     }
     for (int l = D - 1; l >= 1; l--) {
         P.wf_level = l;
@@ -501,8 +507,8 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     }
     P.n_planes = s->stats.n_planes; P.n_lights = s->n_lights; P.n_materials = s->n_materials;
     P.trav_stack_entries = std::max<uint32_t>(s->stats.max_depth + 1, 2);
-    // 8-byte slots for LDS-resident scenes, 6-byte slots for scenes read from HBM (p3d_traverse.h)
-    P.trav_stack_dwords = P.trav_stack_entries * (lds_scene ? 128u : 96u);
+    // 8-byte slots for LDS-resident scenes, 4-byte slots for scenes read from HBM (p3d_traverse.h)
+    P.trav_stack_dwords = P.trav_stack_entries * (lds_scene ? 128u : kHbmStackDwordsPerEntry);
     memcpy(P.bg, s->bg, sizeof P.bg);
     memcpy(P.eye, cam->eye, sizeof P.eye); memcpy(P.u, cam->u, sizeof P.u);
     memcpy(P.v, cam->v, sizeof P.v); memcpy(P.n, cam->n, sizeof P.n);
@@ -746,7 +752,11 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
             p3d_scene::Workspace& w = s->ws[ln];
             for (int l = 2; l <= D; l++) HIP_TRY(w.rays[l].ensure((shard_px << (l - 1)) * kShards * sizeof(RayRec)));
             for (int l = 1; l <= D - 1; l++) HIP_TRY(w.nodes[l].ensure((shard_px << (l - 1)) * kShards * sizeof(NodeRec)));
-            HIP_TRY(w.counts.ensure((size_t)2 * (kMaxDepth + 2) * kShards * sizeof(uint32_t)));
+            if (!w.counts.p) {   // counters + the alternating level-1 sets + the two parity words (64 words apart)
+                const size_t words = (size_t)2 * (kMaxDepth + 2) * kShards + 4 * kShards + 64;
+                HIP_TRY(w.counts.ensure(words * sizeof(uint32_t)));
+                HIP_TRY(launch_clear_words((uint32_t*)w.counts.p, (uint32_t)words, s->stream));   // once; ordered before the lanes' fork
+            }
             if (stochastic)
                 for (int l = 2; l <= D; l++) HIP_TRY(w.rng[l].ensure((shard_px << (l - 1)) * kShards * sizeof(uint32_t)));
         }

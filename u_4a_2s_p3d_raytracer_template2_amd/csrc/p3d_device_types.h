@@ -109,7 +109,13 @@ struct LaunchParams {
     uint32_t wf_cap_in, wf_cap_out, wf_ncap_parent, wf_ncap_self;    // entries per shard
     const RayRec* wf_rays_in;  const uint32_t* wf_count_in;      // level wf_level queue
     RayRec* wf_rays_out;       uint32_t* wf_count_out;           // level wf_level + 1 queue
-    uint32_t* wf_clear; uint32_t wf_clear_words;                  // (unused)
+    // Counters without a clearing launch and without host state: the two counter arrays the level-1 launch fills --
+    // level-2 rays, level-1 nodes -- exist twice (wf_alt: [set][0 = rays, 1 = nodes][shard]) and the set in use
+    // alternates per pass under two device words: the level-1 launch reads A = wf_ctrl[0] (nobody writes it then),
+    // copies it to B = wf_ctrl[32] for the later launches of the pass, and clears the OTHER set and every deeper
+    // level's counters (wf_clear: all dead since the previous pass ended); the level-2 launch sets A = 1 - B.
+    uint32_t* wf_clear; uint32_t wf_clear_words;
+    uint32_t* wf_alt; uint32_t* wf_ctrl;
     NodeRec* wf_nodes_parent;                                     // level wf_level - 1 nodes
     NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
     float* wf_planes; uint64_t wf_plane_stride;                   // [sample][local px][3] clamped sample colours; floats per plane

@@ -122,15 +122,25 @@ struct Shard {
     NodeRec* nodes_parent; NodeRec* nodes_self; uint32_t* ncount_self;
     const uint32_t* rng_in; uint32_t* rng_out;     // random-stream keys of the queued rays, or nullptr
 };
-__device__ __forceinline__ Shard shard_of(const LaunchParams& P, uint32_t s) {
+// the counter arrays of this launch under pass parity `par` (see LaunchParams::wf_alt)
+__device__ __forceinline__ const uint32_t* count_in_array(const LaunchParams& P, uint32_t par) {
+    return P.wf_level == 2 ? P.wf_alt + (size_t)(par * 2u) * (uint32_t)P.wf_shards : P.wf_count_in;
+}
+__device__ __forceinline__ uint32_t* count_out_array(const LaunchParams& P, uint32_t par) {
+    return P.wf_level == 1 ? P.wf_alt + (size_t)(par * 2u) * (uint32_t)P.wf_shards : P.wf_count_out;
+}
+__device__ __forceinline__ uint32_t* ncount_self_array(const LaunchParams& P, uint32_t par) {
+    return P.wf_level == 1 ? P.wf_alt + (size_t)(par * 2u + 1u) * (uint32_t)P.wf_shards : P.wf_ncount_self;
+}
+__device__ __forceinline__ Shard shard_of(const LaunchParams& P, uint32_t s, uint32_t par) {
     Shard h;
     h.rays_in = P.wf_rays_in ? P.wf_rays_in + (size_t)s * P.wf_cap_in : nullptr;
-    h.count_in = P.wf_count_in ? P.wf_count_in[s] : 0u;
+    h.count_in = P.wf_rays_in ? count_in_array(P, par)[s] : 0u;
     h.rays_out = P.wf_rays_out ? P.wf_rays_out + (size_t)s * P.wf_cap_out : nullptr;
-    h.count_out = P.wf_count_out + s;
+    h.count_out = count_out_array(P, par) + s;
     h.nodes_parent = P.wf_nodes_parent ? P.wf_nodes_parent + (size_t)s * P.wf_ncap_parent : nullptr;
     h.nodes_self = P.wf_nodes_self ? P.wf_nodes_self + (size_t)s * P.wf_ncap_self : nullptr;
-    h.ncount_self = P.wf_ncount_self + s;
+    h.ncount_self = ncount_self_array(P, par) + s;
     h.rng_in = P.wf_rng_in ? P.wf_rng_in + (size_t)s * P.wf_cap_in : nullptr;
     h.rng_out = P.wf_rng_out ? P.wf_rng_out + (size_t)s * P.wf_cap_out : nullptr;
     return h;
@@ -250,11 +260,18 @@ __device__ __forceinline__ void stamp(const LaunchParams& P, int tile, int k) {
 // microsecond), 110 us with 64 counters on separate lines, against 50 us for this plain grid.)
 template <bool COUNT, bool LDS, int WALK, int OCC, bool STOCH = false>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel(const LaunchParams P) {
+    const uint32_t par = P.wf_ctrl[0] & 1u;                     // this pass's counter set (LaunchParams::wf_alt)
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) P.wf_ctrl[32] = par;
+        for (uint32_t i = threadIdx.x; i < P.wf_clear_words; i += blockDim.x) P.wf_clear[i] = 0u;
+        uint32_t* other = P.wf_alt + (size_t)((1u - par) * 2u) * (uint32_t)P.wf_shards;
+        for (uint32_t i = threadIdx.x; i < 2u * (uint32_t)P.wf_shards; i += blockDim.x) other[i] = 0u;
+    }
     const typename View<LDS>::type sv = View<LDS>::make(P);
     int x, y, row, tile;
     const bool valid = tile_pixel(P, x, y, row, &tile);
     if (__ballot(valid) == 0) return;
-    const Shard sh = shard_of(P, (uint32_t)tile % (uint32_t)P.wf_shards);
+    const Shard sh = shard_of(P, (uint32_t)tile % (uint32_t)P.wf_shards, par);
     const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
     const size_t p = (size_t)row * P.res_x + x;
@@ -296,13 +313,16 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
     const uint32_t S = (uint32_t)P.wf_shards;
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const int lane = threadIdx.x & 63;
+    const uint32_t par = P.wf_ctrl[32] & 1u;                    // set by the level-1 launch of this pass
+    if (P.wf_level == 2 && blockIdx.x == 0 && threadIdx.x == 0) P.wf_ctrl[0] = 1u - par;   // the next pass takes the other set
+    const uint32_t* counts_in = count_in_array(P, par);
     if (LDS) {
         // Scenes served from LDS: full 64-ray batches, numbered THROUGH all shards (the host launches S == 64
         // shards, one count per lane: batches per shard, wave-wide prefix sum), batch b goes to wave b % n_waves.
         // A deeper level of a 1080p frame is ~1.15 batches per resident-at-4-per-SIMD wave, and a launch lasts as
         // long as its busiest wave: with the grid sized to what can be RESIDENT (host: occupancy query) and every
         // wave owning at most one batch whichever shard it is in, the level costs one ray step instead of two.
-        const uint32_t c = (uint32_t)lane < S ? P.wf_count_in[lane] : 0u;
+        const uint32_t c = (uint32_t)lane < S ? counts_in[lane] : 0u;
         const uint32_t nb = (c + 63u) >> 6;
         uint32_t incl = nb;
 #pragma unroll
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
         for (uint32_t b = wave_id; b < total; b += n_waves) {
             const int s = (int)__builtin_ctzll(__ballot(incl > b));  // the shard batch b belongs to
             const uint32_t first = __shfl(incl - nb, s);             // batches in the shards before it
-            const Shard sh = shard_of(P, (uint32_t)s);
+            const Shard sh = shard_of(P, (uint32_t)s, par);
             const uint32_t i = (b - first) * 64u + lane;
             const bool valid = i < sh.count_in;
             uint32_t link = 0, rng = 0; float ior_1 = 1.0f;
@@ -343,13 +363,13 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
         const uint32_t w0 = (blockIdx.x * blockDim.x) >> 6, nw = blockDim.x >> 6;
         bool any = false;
         for (uint32_t w = w0; w < w0 + nw; w++) {
-            const uint32_t c = P.wf_count_in[w % S];
+            const uint32_t c = counts_in[w % S];
             if ((w / S) * wave_width(c, per_shard, (uint32_t)P.wf_min_width) < c) any = true;
         }
         if (!any) return;
     }
     const typename View<LDS>::type sv = View<LDS>::make(P);
-    const Shard sh = shard_of(P, wave_id % S);
+    const Shard sh = shard_of(P, wave_id % S, par);
     const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
     const uint32_t width = wave_width(sh.count_in, per_shard, (uint32_t)P.wf_min_width);
@@ -376,7 +396,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
 // walk one level back up: node = color + (refl_ret*KR*spec + refr_ret*(1-KR)), RT/main.cpp:719
 __global__ __launch_bounds__(256) void wf_resolve_kernel(const LaunchParams P) {
     const uint32_t S = (uint32_t)P.wf_shards;
-    const Shard sh = shard_of(P, blockIdx.x % S);
+    const Shard sh = shard_of(P, blockIdx.x % S, P.wf_ctrl[32] & 1u);
     const uint32_t count = *sh.ncount_self;
     const uint32_t per_shard = gridDim.x / S;
     const GlobalScene gv = View<false>::make(P);

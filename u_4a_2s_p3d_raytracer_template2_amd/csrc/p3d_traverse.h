@@ -82,8 +82,9 @@ template <class SV> __device__ __forceinline__ void sv_mat(const SV& sv, uint32_
 // are skipped without touching memory).  Two layouts behind one interface:
 //  WideStack  8-byte entries {ref, t as f32}: one ds_write_b64 / ds_read_b64.  Scenes rendered from
 //             an LDS copy -- their trees are a few levels deep and the kernels are issue-bound.
-//  SlimStack  6-byte entries: refs in one [slot][lane] plane, t truncated to its upper 16 bits in a
-//             second one.  Scenes read from HBM -- a depth-25 stack is 12.8 KB per wave wide, 9.6 KB
+//  SlimStack  (round 1; superseded by RefStack below, kept for comparison builds: -DP3D_HBM_STACK=SlimStack
+//             -DP3D_HBM_STACK_DWORDS=96u) 6-byte entries: refs in one [slot][lane] plane, t truncated to its upper
+//             16 bits in a second one.  Scenes read from HBM -- a depth-25 stack is 12.8 KB per wave wide, 9.6 KB
 //             slim, which is the difference between 12 and 16 resident waves per CU for kernels that
 //             wait on memory most of the time.  Truncation moves a positive t towards zero and best.t
 //             is never negative, so a stored distance never exceeds the true one by more than it may:
@@ -137,9 +138,28 @@ struct SlimStack {
         return true;
     }
 };
+// 4-byte entries: node refs only.  A popped node is always visited; if it lies behind the best hit so far its
+// children fail their slab tests (one wasted fetch), which is the price for 6.4 instead of 9.6 KB of LDS per wave
+// at tree depth 25 -- scenes read from HBM are bound by how many waves are in flight to hide fetch latency.
+struct RefStack {
+    uint32_t* refs; int sp;
+    __device__ __forceinline__ explicit RefStack(const TravStack& r) : refs(r.region + r.lane), sp(0) {}
+    __device__ __forceinline__ void push(int32_t node, float) { refs[sp * 64] = (uint32_t)node; sp++; }
+    __device__ __forceinline__ bool pop(float, int32_t& node) { return pop(node); }
+    __device__ __forceinline__ bool pop(int32_t& node) {
+        if (sp == 0) return false;
+        sp--; node = (int32_t)refs[sp * 64];
+        return true;
+    }
+};
+// measured, 1920x1080 depth 4: dragon 2.12 -> 1.88 ms (tree), 10^6 primitives 3.32 -> 3.19 ms (wavefront) and
+// 5.3 -> 4.3 ms (tile) against the 6-byte SlimStack: more resident waves beat pop-time pruning
+#ifndef P3D_HBM_STACK
+#define P3D_HBM_STACK RefStack
+#endif
 template <class SV> struct StackOf;
 template <> struct StackOf<LdsScene> { typedef WideStack type; };
-template <> struct StackOf<GlobalScene> { typedef SlimStack type; };
+template <> struct StackOf<GlobalScene> { typedef P3D_HBM_STACK type; };
 
 struct SlabRay { float kx, ky, kz, ix, iy, iz; };     // i = 1/d, k = -o/d: a plane's distance is fma(plane, i, k)
 
