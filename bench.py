@@ -317,6 +317,8 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="pathtracer workload: samples (frames) per step")
     args = ap.parse_args()
 
+    # the host driver only supports dmabuf IPC: without this RCCL cannot share buffers between the ranks' processes
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     from conftest import scene_path
@@ -340,17 +342,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm = None
-    if rehearsal:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    elif world > 1:
+    if world > 1:
         # control plane only: the communicator id, barriers and the timing reduction go through gloo;
         # every byte of image data moves through p3d_gather (RCCL) below
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         ident = [P.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
-        comm = P.Comm.create(ident[0], rank, world, local_rank)
+        assert isinstance(ident[0], bytes) and len(ident[0]) == 128
+        if not rehearsal:
+            comm = P.Comm.create(ident[0], rank, world, local_rank)
 
     if args.workload == "pathtracer":
         if rehearsal:

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -169,6 +170,8 @@ struct p3d_scene {
     bool timer_open = false;
     size_t lds_prepared = 0;
     int xcd_chunk = 1;
+    int frame_streams = 1;               // bands of a one-sample frame run concurrently on this many streams (experiment knob)
+    int resolve_blocks_per_shard = 16;   // a resolve launch is latency-bound: few nodes per thread, many threads
     unsigned long long* dbg_stamps = nullptr;
     int occupancy = 0;     // 0 = compiler default register budget, else 5 / 6 / 8 waves per SIMD
 };
@@ -269,6 +272,8 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
 
     p3d_scene* s = new p3d_scene();
     s->device = device;
+    if (const char* e = getenv("P3D_FRAME_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= kLanes) s->frame_streams = v; }
+    if (const char* e = getenv("P3D_RESOLVE_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 64) s->resolve_blocks_per_shard = v; }   // tuning experiments
     auto bail = [&](hipError_t e, const char* what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(e);
         p3d_scene_destroy(s);
@@ -453,7 +458,7 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
         P.wf_level = l;
         P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
         P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = l > 1 ? cap(l - 1) : 0;
-        HIP_TRY(launch_wf_resolve(P, kShards * 4, stream));
+        HIP_TRY(launch_wf_resolve(P, kShards * (unsigned)s->resolve_blocks_per_shard, stream));
     }
     return P3D_OK;
 }
@@ -535,6 +540,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         P.grid_blocks = ((chunks + 7) / 8) * 8 * P.xcd_chunk;
     }
     P.counters = s->d_counters;
+    if (const char* e = getenv("P3D_DEBUG_SKIP")) P.dbg_skip = (uint32_t)atoi(e);      // read by -DP3D_DEBUG_SKIP builds only
     P.dbg_stamps = s->dbg_stamps;
     P.wf_min_width = lds_scene ? 64 : 8;
 
@@ -621,12 +627,15 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     // wavefront bands: worst-case queues for a band of tile rows must fit the workspace budget
     const size_t tile_row_px = (size_t)P.tiles_x * 64 * P.wg_waves;
     // sample passes of one frame run on up to kLanes streams, each with its share of the budget
-    const int lanes = prm->spp > 0 ? std::min(kLanes, prm->spp * prm->spp) : 1;
+    // ... and a one-sample frame may be cut into frame_streams bands of tile rows that run concurrently the same way
+    const int frame_streams = (prm->spp == 0 && lds_scene) ? std::max(1, std::min(kLanes, s->frame_streams)) : 1;
+    const int lanes = prm->spp > 0 ? std::min(kLanes, prm->spp * prm->spp) : frame_streams;
     size_t wf_bpp = wavefront_bytes_per_pixel(prm->max_depth);
     if (stochastic) for (int l = 2; l <= prm->max_depth; l++) wf_bpp += ((size_t)1 << (l - 1)) * sizeof(uint32_t);
     size_t band_tile_rows = wf_bpp ? budget / lanes / (wf_bpp * tile_row_px) : (size_t)P.tiles_y;
     if (wf_bpp == 0) band_tile_rows = (size_t)P.tiles_y;
     band_tile_rows = std::min<size_t>(band_tile_rows, (size_t)P.tiles_y);
+    if (frame_streams > 1) band_tile_rows = std::min<size_t>(band_tile_rows, ((size_t)P.tiles_y + frame_streams - 1) / frame_streams);
     const bool wavefront_ok = band_tile_rows > 0;
 
     int sched = SCHED_TILE;
@@ -769,11 +778,13 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
             HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
             for (int ln = 1; ln < lanes; ln++) HIP_TRY(hipStreamWaitEvent(s->lane_stream[ln], s->ev_fork, 0));
         }
+        int task = 0;
         for (int smp = 0; smp < P.wf_nsamples; smp++) {
             P.wf_sample = smp;
-            const int ln = smp % lanes;
-            const hipStream_t lane_stream = ln == 0 ? s->stream : s->lane_stream[ln];
-            for (size_t r0 = 0; r0 < (size_t)P.tiles_y; r0 += band_tile_rows) {
+            for (size_t r0 = 0; r0 < (size_t)P.tiles_y; r0 += band_tile_rows, task++) {
+                // sample passes go round the lanes; so do the bands of a one-sample frame cut for concurrency
+                const int ln = (prm->spp > 0 ? smp : task) % lanes;
+                const hipStream_t lane_stream = ln == 0 ? s->stream : s->lane_stream[ln];
                 LaunchParams B = P;
                 B.wf_tile_row0 = (int32_t)r0;
                 B.wf_tile_rows = (int32_t)std::min<size_t>(band_tile_rows, (size_t)P.tiles_y - r0);

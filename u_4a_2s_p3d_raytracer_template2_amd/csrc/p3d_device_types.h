@@ -116,6 +116,7 @@ struct LaunchParams {
     // level's counters (wf_clear: all dead since the previous pass ended); the level-2 launch sets A = 1 - B.
     uint32_t* wf_clear; uint32_t wf_clear_words;
     uint32_t* wf_alt; uint32_t* wf_ctrl;
+    uint32_t dbg_skip;                // diagnostic builds only (P3D_DEBUG_SKIP): 1 = no shading after the closest hit, 2 = no shadow queries
     NodeRec* wf_nodes_parent;                                     // level wf_level - 1 nodes
     NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
     float* wf_planes; uint64_t wf_plane_stride;                   // [sample][local px][3] clamped sample colours; floats per plane

@@ -159,6 +159,9 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
     o.color = mk(0.0f, 0.0f, 0.0f);
     o.ret = o.color;
     o.refl.o = o.color; o.refl.d = o.color; o.refr.o = o.color; o.refr.d = o.color;
+#ifdef P3D_DEBUG_SKIP
+    if (P.dbg_skip == 1u) { o.ret = mk(h.t, 0.0f, 0.0f); return o; }
+#endif
     const bool hit = live && h.ref != 0xFFFFFFFFu;
     if (__ballot(hit) == 0) {                     // whole wave missed (sky tiles): nothing to light
         o.ret = mk(P.bg[0], P.bg[1], P.bg[2]);
@@ -181,7 +184,11 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
         for (uint32_t i = 0; i < ln; i++) {
             const float4 lpos = reinterpret_cast<const float4*>(P.lights + l0 + i)[0];
             V3 L = sub(light_position<STOCH>(P, lpos, l0 + i, rng, sample), hit_point);
+#ifdef P3D_DEBUG_SKIP
+            const bool need = hit && dot(L, normal) > 0.0f && P.dbg_skip != 2u;
+#else
             const bool need = hit && dot(L, normal) > 0.0f;              // RT/main.cpp:476
+#endif
             if (light_occluded<COUNT, WALK>(P, sv, L, precise, need, tc, ctr)) occluded |= (1ull << i);
         }
         if (hit) {
