@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Stream schedule against the other schedules: same bits, same counters, time per frame (GPU box tool).
+usage: python tools/stream_probe.py [--quick]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from conftest import scene_path  # noqa: E402
+import u_4a_2s_p3d_raytracer_template2_amd as P  # noqa: E402
+from u_4a_2s_p3d_raytracer_template2_amd import synthetic as S, api  # noqa: E402
+import torch  # noqa: E402
+
+quick = "--quick" in sys.argv
+cases = [("mount_low", 640, 360, 4, 2), ("balls_low", 512, 512, 3, 0), ("balls_medium", 400, 300, 4, 2),
+         ("dragon", 1920, 1080, 4, 2)]
+if not quick:
+    cases += [("synthetic:100000", 1920, 1080, 4, 2), ("synthetic:1000000", 1920, 1080, 4, 2)]
+bad = 0
+for name, w, h, depth, accel in cases:
+    if name.startswith("synthetic:"):
+        n = int(name.split(":")[1])
+        hs = P.HostScene(S.camera_p3f("/tmp/synth_camera.p3f", w, h))
+        cam = hs.camera()
+        desc, keep = api.make_desc(*S.arrays(n))
+        ds = P.DeviceScene(desc, keepalive=keep)
+    else:
+        hs = P.HostScene(scene_path(name))
+        hs.set_resolution(w, h)
+        cam = hs.camera()
+        ds = P.DeviceScene.from_host(hs)
+    ref = None
+    for sched in ("tile", "wavefront", "tree", "stream"):
+        kw = dict(max_depth=depth, accel=accel, no_lds=True, **{sched: True})
+        r = ds.render(cam, counters=True, **kw)
+        c = ds.counters()
+        buf = torch.zeros((h + 16, w, 3), dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            ds.render_device(cam, rgb8_ptr=buf.data_ptr(), **kw)
+        nrep = 20 if w * h < 1000000 else 10
+        ds.timer_begin()
+        for _ in range(nrep):
+            ds.render_device(cam, rgb8_ptr=buf.data_ptr(), **kw)
+        ms = ds.timer_end() / nrep
+        img = buf.cpu().numpy()[:h]
+        same = "ref"
+        if ref is None:
+            ref = (r, c, img)
+        else:
+            ok = (np.array_equal(r["rgb8"], ref[0]["rgb8"]) and np.array_equal(r["rgb32f"].view(np.uint32), ref[0]["rgb32f"].view(np.uint32))
+                  and np.array_equal(r["hit_id"], ref[0]["hit_id"]) and np.array_equal(img, ref[2]))
+            okc = all(c[k] == ref[1][k] for k in ("closest_queries", "shadow_queries", "pixels", "rays"))
+            same = "bits=%s counters=%s" % (ok, okc)
+            if not (ok and okc):
+                bad += 1
+                print("   counters", {k: (c[k], ref[1][k]) for k in c if c[k] != ref[1][k]})
+                print("   differing px", int((r["rgb8"] != ref[0]["rgb8"]).any(axis=-1).sum()), "hit", int((r["hit_id"] != ref[0]["hit_id"]).sum()))
+        print("%-18s %4dx%-4d d%d a%d %-9s (%s) %.4f ms  %.0f Mrays/s  %s" % (name, w, h, depth, accel, sched, ds.last_schedule(), ms, c["rays"] / ms / 1e3, same), flush=True)
+    del ds
+print("MISMATCHES", bad)
+sys.exit(1 if bad else 0)

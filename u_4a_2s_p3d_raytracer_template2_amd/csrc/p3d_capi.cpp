@@ -26,6 +26,9 @@ hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, int wa
 hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, int walk, int occ, unsigned waves,
                                hipStream_t stream);
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream);
+hipError_t extend_resident_waves(const LaunchParams& P, bool count, bool any, int occ, unsigned* waves);
+hipError_t launch_wf_extend(const LaunchParams& P, bool count, bool any, int occ, unsigned waves, hipStream_t stream);
+hipError_t launch_wf_shade(const LaunchParams& P, bool count, bool defer, unsigned waves, hipStream_t stream);
 hipError_t launch_clear_words(uint32_t* p, uint32_t n, hipStream_t stream);
 hipError_t wf_resident_waves(const LaunchParams& P, bool primary, bool count, bool lds, int walk, int occ, unsigned* waves);
 size_t tile_kernel_lds_bytes(const LaunchParams& P, bool lds);
@@ -60,6 +63,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per CU
 constexpr int kMaxDepth = 16;
+constexpr size_t kLdsSceneLimit = 24 * 1024;
 #ifndef P3D_HBM_STACK_DWORDS
 #define P3D_HBM_STACK_DWORDS 64u      // per entry per wave: RefStack 64 (4-byte entries; p3d_traverse.h), SlimStack 96
 #endif
@@ -102,7 +106,9 @@ struct RawBuf {
 struct p3d_scene {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    DevBuf<uint32_t> blob;              // nodes | leaf refs | spheres | sphere meta | tris | boxes | materials
+    DevBuf<uint32_t> blob;              // leaf records | spheres | sphere meta | tris | boxes | materials [| f32 nodes: LDS scenes]
+    DevBuf<QNode> qnodes;               // 32-byte node pairs: what kernels that read the scene from HBM walk
+    float q_scale[3] = {1, 1, 1}, q_base[3] = {0, 0, 0};
     uint32_t blob_quads = 0;
     uint32_t off_nodes = 0, off_leaves = 0, off_spheres = 0, off_sphere_meta = 0, off_tris = 0, off_boxes = 0, off_mats = 0;
     DevBuf<PlaneRec> planes;
@@ -114,7 +120,8 @@ struct p3d_scene {
     GridHost grid_info; bool grid_ready = false;
     DevBuf<LightRec> soft_lights;          // 16 sub-lights per light, built on first use (SOFT_SHADOW, spp == 0)
     std::vector<LightRec> host_lights;
-    size_t lds_scene_limit = 24 * 1024;  // blobs up to this size are rendered from an LDS copy
+    size_t lds_scene_limit = kLdsSceneLimit;  // blobs up to this size are rendered from an LDS copy
+    bool lds_capable = false;            // ... and then carry the f32 nodes the LDS walk reads
     int last_schedule = -1;
     bool unit_rays_only = false;         // built with cull_never_hit: cannot serve un-normalised (NONE-mode) shadow rays
     uint32_t packet_node_limit = 64;     // trees up to this many node pairs use the wave-wide walk
@@ -130,11 +137,20 @@ struct p3d_scene {
     struct Workspace {
         RawBuf rays[kMaxDepth + 2], nodes[kMaxDepth + 2], counts;   // counts: cleared by a kernel in front of every pass
         RawBuf rng[kMaxDepth + 2];           // random-stream keys of the queued rays (stochastic features)
+        // stream schedule: hit records and occlusion words of the level being traced, its shadow queue, block cursors
+        RawBuf hits, occl, jobs, xq_ctrl;
+        size_t held() const {
+            size_t b = hits.cap + occl.cap + jobs.cap;
+            for (auto& q : rays) b += q.cap;
+            for (auto& q : nodes) b += q.cap;
+            for (auto& q : rng) b += q.cap;
+            return b;
+        }
         void release() {
             for (auto& b : rays) b.release();
             for (auto& b : nodes) b.release();
             for (auto& b : rng) b.release();
-            counts.release();
+            counts.release(); hits.release(); occl.release(); jobs.release(); xq_ctrl.release();
         }
     } ws[kLanes];
     RawBuf wf_planes;                        // [sample][local px][3] clamped sample colours (spp > 0)
@@ -143,6 +159,8 @@ struct p3d_scene {
     RawBuf tile_ws, tile_ctrl;
     struct { uint32_t key = 0xFFFFFFFFu; size_t lds = 0; int blocks = 0; } tile_occ;   // cached occupancy query
     struct { uint32_t key = 0xFFFFFFFFu; uint32_t stack = 0; unsigned waves = 0, primary_waves = 0; } wf_occ;                 // ... of the deeper-level kernel
+    struct { uint32_t key = 0xFFFFFFFFu; uint32_t stack = 0; unsigned waves[2] = {0, 0}; } x_occ;                             // ... of the extend kernels
+    int stream_refill = 16, stream_min_blocks = 2, stream_occ = 0;   // stream schedule knobs (see LaunchParams::xq_refill)
     hipStream_t lane_stream[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     // upper limit of the workspace one frame may allocate (wavefront schedule: worst-case level queues of a band
@@ -264,7 +282,13 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
         build_bvh(F.build_prims, bo, nodes, refs, bs);
     }
     TypedLeaves TL;
-    type_leaves(nodes, refs, F, TL);
+    // Scenes small enough to be rendered from an LDS copy keep a record per leaf; the others name single-type leaves
+    // in the reference itself (p3d_traverse.h: sv_leaf).  Upper bound of the blob with a record per leaf:
+    const size_t blob_bound = nodes.size() * (sizeof(NodePair) + 2 * sizeof(LeafRec)) + 16 + F.spheres.size() * (sizeof(SphereRec) + sizeof(PrimMeta)) +
+                              F.tris.size() * sizeof(TriRec) + F.boxes.size() * sizeof(BoxRec) + F.materials.size() * sizeof(MaterialRec) + 7 * 16;
+    const bool small_scene = blob_bound <= kLdsSceneLimit;
+    type_leaves(nodes, refs, F, TL, !small_scene);
+    if (TL.overflow) return fail(P3D_ERR_LIMIT, "too many mixed-type leaves");
     std::vector<SphereRec>& spheres = F.spheres; std::vector<PrimMeta>& sphere_meta = F.sphere_meta;
     std::vector<TriRec>& tris = F.tris; std::vector<BoxRec>& boxes = F.boxes;
     std::vector<PlaneRec>& planes = F.planes; std::vector<PrimMeta>& plane_meta = F.plane_meta;
@@ -301,15 +325,25 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
             if (bytes) memcpy(blob.data() + at, data, bytes);
             return off;
         };
-        s->off_nodes = section(nodes.data(), nodes.size() * sizeof(NodePair));
         s->off_leaves = section(TL.leaves.data(), TL.leaves.size() * sizeof(LeafRec));
         s->off_spheres = section(spheres.data(), spheres.size() * sizeof(SphereRec));
         s->off_sphere_meta = section(sphere_meta.data(), sphere_meta.size() * sizeof(PrimMeta));
         s->off_tris = section(tris.data(), tris.size() * sizeof(TriRec));
         s->off_boxes = section(boxes.data(), boxes.size() * sizeof(BoxRec));
         s->off_mats = section(mats.data(), mats.size() * sizeof(MaterialRec));
+        // the f32 nodes only travel with scenes small enough to be rendered from an LDS copy of the blob
+        if (small_scene && blob.size() * 4 + nodes.size() * sizeof(NodePair) <= s->lds_scene_limit) {
+            s->off_nodes = section(nodes.data(), nodes.size() * sizeof(NodePair));
+            s->lds_capable = true;
+        }
         s->blob_quads = (uint32_t)(blob.size() / 4);
         if ((e = s->blob.upload(blob)) != hipSuccess) return bail(e, "upload scene blob");
+    }
+    {
+        QuantisedNodes Q;
+        quantise_nodes(nodes, Q);
+        if ((e = s->qnodes.upload(Q.nodes)) != hipSuccess) return bail(e, "upload nodes");
+        memcpy(s->q_scale, Q.scale, sizeof s->q_scale); memcpy(s->q_base, Q.base, sizeof s->q_base);
     }
     if ((e = s->planes.upload(planes)) != hipSuccess) return bail(e, "upload planes");
     if ((e = s->plane_meta.upload(plane_meta)) != hipSuccess) return bail(e, "upload plane meta");
@@ -332,7 +366,7 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     s->stats.n_boxes = (uint32_t)boxes.size(); s->stats.n_planes = (uint32_t)planes.size();
     s->stats.n_culled = n_culled;
     s->unit_rays_only = n_culled > 0;
-    s->stats.device_bytes = s->blob.bytes() + s->planes.bytes() + s->plane_meta.bytes() + s->lights.bytes();
+    s->stats.device_bytes = s->blob.bytes() + s->qnodes.bytes() + s->planes.bytes() + s->plane_meta.bytes() + s->lights.bytes();
     *out = s;
     return P3D_OK;
 }
@@ -342,7 +376,7 @@ int p3d_scene_destroy(p3d_scene* s) {
     (void)hipSetDevice(s->device);
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     s->grid_cells.release(); s->grid_items.release();
-    s->blob.release(); s->planes.release(); s->plane_meta.release(); s->lights.release(); s->soft_lights.release();
+    s->blob.release(); s->qnodes.release(); s->planes.release(); s->plane_meta.release(); s->lights.release(); s->soft_lights.release();
     s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release(); s->ray_tab.release();
     for (auto& w : s->ws) w.release();
     s->wf_planes.release(); s->tile_ws.release(); s->tile_ctrl.release();
@@ -400,6 +434,10 @@ size_t wavefront_bytes_per_pixel(int D) {
 
 constexpr int kShards = 64;   // queue shards; spreads the slot-allocation atomics. == the wave size: the deeper-level
                               // kernel holds one shard's count per lane (wf_secondary_kernel)
+// counter buffer of a workspace: [level][shard] ray counts, node counts, shadow-job counts (all cleared by the first
+// launch of a pass), then the two alternating level-1 sets and the parity words (LaunchParams::wf_alt)
+constexpr size_t kCountWords = (size_t)3 * (kMaxDepth + 2) * kShards;
+constexpr size_t kCountBufferWords = kCountWords + 4 * kShards + 64;
 
 // One sample pass over one band of tile rows, level by level (see p3d_kernels.hip).
 // shard_px = pixels a shard can own in this band (worst case), so level l holds at most
@@ -410,13 +448,13 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
     // scenes read from HBM wait on fetches most of the time: a register budget of 6 waves per SIMD measured 3 %
     // faster than the compiler's default there (10^6 primitives 3.19 -> 3.08 ms); LDS scenes keep the default
     const int occ = s->occupancy ? s->occupancy : (lds ? 0 : 6);
-    const size_t n_counts = (size_t)2 * (kMaxDepth + 2) * kShards;
+    const size_t n_counts = (size_t)2 * (kMaxDepth + 2) * kShards;          // (the shadow-job counts belong to the stream schedule)
     uint32_t* counts = (uint32_t*)ws.counts.p;                              // [level][shard] ray counts, then node counts
     // No clearing launch and nothing about a frame in host state (a captured frame can be replayed any number of
     // times): the level-1 launch zeroes what the previous pass left, under a device-side parity -- see
     // LaunchParams::wf_alt.  The buffer is zeroed once, when it is allocated.
     P.wf_clear = counts; P.wf_clear_words = (uint32_t)n_counts;
-    P.wf_alt = counts + n_counts; P.wf_ctrl = counts + n_counts + 4 * kShards;
+    P.wf_alt = counts + kCountWords; P.wf_ctrl = counts + kCountWords + 4 * kShards;
     auto rays = [&](int l) { return (l >= 2 && l <= D) ? (RayRec*)ws.rays[l].p : nullptr; };
     auto nodes = [&](int l) { return (l >= 1 && l <= D - 1) ? (NodeRec*)ws.nodes[l].p : nullptr; };
     auto qcount = [&](int l) { return counts + (size_t)l * kShards; };
@@ -463,6 +501,68 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
     return P3D_OK;
 }
 
+// The same pass in the stream schedule: per level an extend launch (closest hits of the queued rays), a shade launch
+// that queues the hits' shadow queries, an extend launch for those, and the shade launch that finishes the nodes.
+int run_stream_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t stream, LaunchParams P, bool count, size_t shard_px,
+                    bool profile) {
+    const int D = P.max_depth;
+    const int occ = s->stream_occ;
+    uint32_t* counts = (uint32_t*)ws.counts.p;
+    P.wf_clear = counts; P.wf_clear_words = (uint32_t)kCountWords;
+    P.wf_alt = counts + kCountWords; P.wf_ctrl = counts + kCountWords + 4 * kShards;
+    auto rays = [&](int l) { return (l >= 2 && l <= D) ? (RayRec*)ws.rays[l].p : nullptr; };
+    auto nodes = [&](int l) { return (l >= 1 && l <= D - 1) ? (NodeRec*)ws.nodes[l].p : nullptr; };
+    auto qcount = [&](int l) { return counts + (size_t)l * kShards; };
+    auto ncount = [&](int l) { return counts + (size_t)(kMaxDepth + 2 + l) * kShards; };
+    auto jcount = [&](int l) { return counts + (size_t)(2 * (kMaxDepth + 2) + l) * kShards; };
+    auto cap = [&](int l) { return (uint32_t)(shard_px << (l - 1)); };
+    auto rng = [&](int l) { return (P.features && l >= 2 && l <= D) ? (uint32_t*)ws.rng[l].p : nullptr; };
+    P.wf_shards = kShards;
+    P.xq_ctrl = (uint32_t*)ws.xq_ctrl.p; P.xq_hits = (HitRec*)ws.hits.p; P.xq_occl = (uint32_t*)ws.occl.p;
+    P.xq_jobs = (ShadowJob*)ws.jobs.p;
+    P.xq_refill = s->stream_refill; P.xq_min_blocks = s->stream_min_blocks;
+    if (const char* e = getenv("P3D_STREAM_REFILL")) P.xq_refill = atoi(e);            // experiment knobs
+    if (const char* e = getenv("P3D_STREAM_MIN_BLOCKS")) P.xq_min_blocks = atoi(e);
+    double wave_scale = 1.0;
+    if (const char* e = getenv("P3D_STREAM_WAVES_PCT")) wave_scale = atoi(e) / 100.0;
+    {
+        const uint32_t okey = (count ? 1u : 0u) | ((uint32_t)occ << 5);
+        if (s->x_occ.key != okey || s->x_occ.stack != P.trav_stack_dwords) {
+            HIP_TRY(extend_resident_waves(P, count, false, occ, &s->x_occ.waves[0]));
+            HIP_TRY(extend_resident_waves(P, count, true, occ, &s->x_occ.waves[1]));
+            s->x_occ.key = okey; s->x_occ.stack = P.trav_stack_dwords;
+        }
+    }
+    for (int l = 1; l <= D; l++) {
+        P.wf_level = l;
+        P.wf_rays_in = rays(l); P.wf_count_in = l >= 2 ? qcount(l) : nullptr; P.wf_cap_in = l >= 2 ? cap(l) : 0;
+        P.wf_rays_out = rays(l + 1); P.wf_count_out = qcount(l + 1); P.wf_cap_out = cap(l + 1);
+        P.wf_rng_in = rng(l); P.wf_rng_out = rng(l + 1);
+        P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = l >= 2 ? cap(l - 1) : 0;
+        P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
+        P.xq_jcount = jcount(l); P.xq_jcap = cap(l) * std::max<uint32_t>(P.n_lights, 1u);
+        // most blocks of 64 queued rays / shadow queries the level can hold
+        const size_t blocks = l == 1 ? (size_t)P.n_tiles : ((size_t)cap(l) * kShards + 63) / 64;
+        const unsigned xw = (unsigned)std::min<size_t>(blocks, (size_t)(s->x_occ.waves[0] * wave_scale));
+        const unsigned aw = (unsigned)std::min<size_t>(blocks * std::max<uint32_t>(P.n_lights, 1u), (size_t)(s->x_occ.waves[1] * wave_scale));
+        unsigned sw = (unsigned)std::min<size_t>(blocks, (size_t)kShards * 64);
+        sw = std::max<unsigned>(kShards, (sw / kShards) * kShards);               // whole waves per shard
+        if (profile && l == 1) HIP_TRY(hipEventRecord(s->ev_prof[2], stream));
+        HIP_TRY(launch_wf_extend(P, count, false, occ, std::max(1u, xw), stream));
+        if (profile && l == 1) HIP_TRY(hipEventRecord(s->ev_prof[3], stream));
+        HIP_TRY(launch_wf_shade(P, count, false, sw, stream));
+        HIP_TRY(launch_wf_extend(P, count, true, occ, std::max(1u, aw), stream));
+        HIP_TRY(launch_wf_shade(P, count, true, sw, stream));
+    }
+    for (int l = D - 1; l >= 1; l--) {
+        P.wf_level = l;
+        P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
+        P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = l > 1 ? cap(l - 1) : 0;
+        HIP_TRY(launch_wf_resolve(P, kShards * (unsigned)s->resolve_blocks_per_shard, stream));
+    }
+    return P3D_OK;
+}
+
 }  // namespace
 
 int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm, const p3d_outputs* out) {
@@ -484,11 +584,12 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     LaunchParams P;
     memset(&P, 0, sizeof P);
     P.blob = s->blob.p; P.blob_quads = s->blob_quads;
+    P.qnodes = s->qnodes.p; memcpy(P.q_scale, s->q_scale, sizeof P.q_scale); memcpy(P.q_base, s->q_base, sizeof P.q_base);
     P.off_nodes = s->off_nodes; P.off_leaves = s->off_leaves; P.off_spheres = s->off_spheres;
     P.off_sphere_meta = s->off_sphere_meta; P.off_tris = s->off_tris; P.off_boxes = s->off_boxes; P.off_mats = s->off_mats;
     P.planes = s->planes.p; P.plane_meta = s->plane_meta.p; P.lights = s->lights.p;
     // small scenes are rendered from an LDS copy shared by the 4 waves of a 256-thread workgroup
-    const bool lds_scene = !(prm->flags & P3D_FLAG_NO_LDS_SCENE) && (size_t)s->blob_quads * 16 <= s->lds_scene_limit;
+    const bool lds_scene = !(prm->flags & P3D_FLAG_NO_LDS_SCENE) && s->lds_capable;
     P.wg_waves = lds_scene ? 4 : 1;
     // small trees are walked by the whole wave together (packet walk), large ones per lane; GRID mode walks the
     // reference's uniform grid per lane
@@ -582,9 +683,11 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     //   WAVEFRONT  one launch per tree level over the whole frame + resolve launches
     //   TREE       one launch; each lane walks its pixel's whole tree
     // None wins everywhere, so the default is MEASURED per configuration: see SchedulePick below.
-    enum { SCHED_WAVEFRONT = 0, SCHED_TREE = 1, SCHED_TILE = 2 };
-    const uint32_t forced = prm->flags & (P3D_FLAG_TREE_KERNEL | P3D_FLAG_WAVEFRONT | P3D_FLAG_TILE_KERNEL);
-    if (forced & (forced - 1)) return fail(P3D_ERR_ARG, "at most one of P3D_FLAG_TREE_KERNEL / _WAVEFRONT / _TILE_KERNEL");
+    //   STREAM     wavefront with traversal in launches of its own: persistent waves that refill idle lanes (scenes
+    //              read from HBM, per-lane BVH walk, up to 32 lights)
+    enum { SCHED_WAVEFRONT = 0, SCHED_TREE = 1, SCHED_TILE = 2, SCHED_STREAM = 3 };
+    const uint32_t forced = prm->flags & (P3D_FLAG_TREE_KERNEL | P3D_FLAG_WAVEFRONT | P3D_FLAG_TILE_KERNEL | P3D_FLAG_STREAM_KERNELS);
+    if (forced & (forced - 1)) return fail(P3D_ERR_ARG, "at most one of P3D_FLAG_TREE_KERNEL / _WAVEFRONT / _TILE_KERNEL / _STREAM_KERNELS");
     if (stochastic && (prm->flags & P3D_FLAG_TREE_KERNEL))
         return fail(P3D_ERR_ARG, "features with random draws need the tile or the wavefront schedule");
 
@@ -593,7 +696,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         if (memcmp(bkey, s->budget_key, sizeof bkey) != 0) {
             size_t free_b = 0, total_b = 0;
             size_t held = s->tile_ws.cap + s->wf_planes.cap;
-            for (auto& w : s->ws) { for (auto& b : w.rays) held += b.cap; for (auto& b : w.nodes) held += b.cap; for (auto& b : w.rng) held += b.cap; }
+            for (auto& w : s->ws) held += w.held();
             s->budget_avail = s->workspace_budget;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
                 s->budget_avail = std::min<size_t>(s->workspace_budget, (size_t)((double)(free_b + held) * 0.85));
@@ -637,13 +740,24 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     band_tile_rows = std::min<size_t>(band_tile_rows, (size_t)P.tiles_y);
     if (frame_streams > 1) band_tile_rows = std::min<size_t>(band_tile_rows, ((size_t)P.tiles_y + frame_streams - 1) / frame_streams);
     const bool wavefront_ok = band_tile_rows > 0;
+    // stream schedule: the wavefront queues + hit record, occlusion word and n_lights shadow jobs per ray of the widest level
+    const size_t stream_bpp = wf_bpp + ((sizeof(HitRec) + 4 + sizeof(ShadowJob) * std::max<uint32_t>(P.n_lights, 1u)) << (prm->max_depth - 1));
+    size_t stream_band_rows = std::min<size_t>(budget / lanes / (stream_bpp * tile_row_px), (size_t)P.tiles_y);
+    bool stream_ok = !lds_scene && walk == 0 && P.n_lights <= kStreamMaxLights && stream_band_rows > 0;
+    if (stream_ok) {       // a shard's widest queue must fit the 27-bit ray index of a shadow job
+        const size_t spx = ((stream_band_rows * (size_t)P.tiles_x + kShards - 1) / kShards) * 64;
+        if ((spx << (prm->max_depth - 1)) > (size_t)kJobRayMask) stream_ok = false;
+    }
 
     int sched = SCHED_TILE;
     int measuring = -1;                 // schedule this frame is timed as, for the pick below
     if (prm->flags & P3D_FLAG_TREE_KERNEL) sched = SCHED_TREE;
     else if (prm->flags & P3D_FLAG_WAVEFRONT) sched = SCHED_WAVEFRONT;
     else if (prm->flags & P3D_FLAG_TILE_KERNEL) sched = SCHED_TILE;
-    else if (lds_scene) {
+    else if (prm->flags & P3D_FLAG_STREAM_KERNELS) {
+        if (!stream_ok) return fail(P3D_ERR_ARG, "P3D_FLAG_STREAM_KERNELS: needs a scene read from HBM (P3D_FLAG_NO_LDS_SCENE for small ones), accel NONE or BVH, <= 32 lights and a workspace budget that holds one band");
+        sched = SCHED_STREAM;
+    } else if (lds_scene) {
         // scenes served from LDS: by rule (measured once, on BASELINE configs 2 and 4: a one-sample 1080p frame
         // 0.136 ms wavefront / 0.22 tile / 0.22 tree; 4096^2 x 4 samples 5.4 / 5.1 / 11.1 -- with samples the tile
         // schedule needs no per-sample planes and no summing launch).  A timing-based pick is not used here: these
@@ -655,7 +769,10 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         // random primitives: wavefront 3.7, tile 6.1, tree 9.5), so the library MEASURES: the first frames of a
         // configuration run every available schedule twice -- the first time untimed: code-object load,
         // workspace allocation -- and the fastest one stays.  All produce identical bits.
-        const bool avail[3] = {wavefront_ok, !stochastic, tile_ok};
+        // (the stream schedule is opt-in only: measured slower than the best of the three on every scene tried --
+        //  dragon 4.96 ms vs 1.85, 10^5 / 10^6 random primitives 2.87 / 3.55 vs 2.34 / 3.11 -- DESIGN.md)
+        constexpr int NS = 3;
+        const bool avail[NS] = {wavefront_ok, !stochastic, tile_ok};
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(s->stream, &cap);
         p3d_scene::SchedulePick& pk = s->pick;
@@ -663,7 +780,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
                                 (int32_t)((prm->flags & (P3D_FLAG_NO_LDS_SCENE | P3D_FLAG_NO_PACKET | P3D_FLAG_COUNTERS)) | (prm->features << 8))};
         if (cap != hipStreamCaptureStatusNone) {
             // events cannot be read while the stream is being captured: use what is known, measure nothing
-            if (memcmp(key, pk.key, sizeof key) == 0 && pk.step >= 2 * 3) sched = pk.best;
+            if (memcmp(key, pk.key, sizeof key) == 0 && pk.step >= 2 * NS) sched = pk.best;
         } else {
             if (memcmp(key, pk.key, sizeof key) != 0) {
                 memcpy(pk.key, key, sizeof key);
@@ -676,15 +793,15 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
                 if (pk.ms[pk.pending] < 0.0f || ms < pk.ms[pk.pending]) pk.ms[pk.pending] = ms;
                 pk.pending = -1;
             }
-            while (pk.step < 2 * 3 && !avail[pk.step / 2]) pk.step = (pk.step / 2 + 1) * 2;     // skip what cannot run
-            if (pk.step < 2 * 3) {
+            while (pk.step < 2 * NS && !avail[pk.step / 2]) pk.step = (pk.step / 2 + 1) * 2;     // skip what cannot run
+            if (pk.step < 2 * NS) {
                 sched = pk.step / 2;
                 if (pk.step & 1) measuring = sched;
                 pk.step++;
             } else {
-                if (pk.step == 2 * 3) {
+                if (pk.step == 2 * NS) {
                     pk.best = -1;
-                    for (int k = 0; k < 3; k++)
+                    for (int k = 0; k < NS; k++)
                         if (avail[k] && pk.ms[k] >= 0.0f && (pk.best < 0 || pk.ms[k] < pk.ms[pk.best])) pk.best = k;
                     if (pk.best < 0) pk.best = tile_ok ? SCHED_TILE : (wavefront_ok ? SCHED_WAVEFRONT : SCHED_TREE);
                     pk.step++;
@@ -694,10 +811,12 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         }
     }
     // a schedule whose workspace does not fit falls back: tile -> wavefront (bands) -> tree
+    if (sched == SCHED_STREAM && !stream_ok) sched = SCHED_TILE;
     if (sched == SCHED_TILE && !tile_ok) sched = wavefront_ok ? SCHED_WAVEFRONT : SCHED_TREE;
     if (sched == SCHED_WAVEFRONT && !wavefront_ok) sched = SCHED_TREE;
     if (sched == SCHED_TREE && stochastic) return fail(P3D_ERR_LIMIT, "workspace budget too small for the schedules the features need");
-    const bool use_tree = sched == SCHED_TREE, use_tile = sched == SCHED_TILE;
+    const bool use_tree = sched == SCHED_TREE, use_tile = sched == SCHED_TILE, use_stream = sched == SCHED_STREAM;
+    if (use_stream) band_tile_rows = stream_band_rows;
     s->last_schedule = sched;
     size_t lds = use_tree ? tree_kernel_lds_bytes(P, lds_scene) : use_tile ? tile_kernel_lds_bytes(PT, lds_scene) : wavefront_lds_bytes(P, lds_scene);
     if (lds > kMaxLdsBytes) return fail(P3D_ERR_LIMIT, "BVH depth / max_depth need more LDS than a CU has");
@@ -762,12 +881,22 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
             for (int l = 2; l <= D; l++) HIP_TRY(w.rays[l].ensure((shard_px << (l - 1)) * kShards * sizeof(RayRec)));
             for (int l = 1; l <= D - 1; l++) HIP_TRY(w.nodes[l].ensure((shard_px << (l - 1)) * kShards * sizeof(NodeRec)));
             if (!w.counts.p) {   // counters + the alternating level-1 sets + the two parity words (64 words apart)
-                const size_t words = (size_t)2 * (kMaxDepth + 2) * kShards + 4 * kShards + 64;
+                const size_t words = kCountBufferWords;
                 HIP_TRY(w.counts.ensure(words * sizeof(uint32_t)));
                 HIP_TRY(launch_clear_words((uint32_t*)w.counts.p, (uint32_t)words, s->stream));   // once; ordered before the lanes' fork
             }
             if (stochastic)
                 for (int l = 2; l <= D; l++) HIP_TRY(w.rng[l].ensure((shard_px << (l - 1)) * kShards * sizeof(uint32_t)));
+            if (use_stream) {
+                const size_t widest = (shard_px << (D - 1)) * kShards;           // rays of the widest level (>= the band's pixels)
+                HIP_TRY(w.hits.ensure(widest * sizeof(HitRec)));
+                HIP_TRY(w.occl.ensure(widest * sizeof(uint32_t)));
+                HIP_TRY(w.jobs.ensure(widest * std::max<uint32_t>(P.n_lights, 1u) * sizeof(ShadowJob)));
+                if (!w.xq_ctrl.p) {
+                    HIP_TRY(w.xq_ctrl.ensure(64 * 64 * sizeof(uint32_t)));           // one 256-byte line per shard cursor
+                    HIP_TRY(launch_clear_words((uint32_t*)w.xq_ctrl.p, 64 * 64, s->stream));
+                }
+            }
         }
         if (prm->spp > 0) {
             HIP_TRY(s->wf_planes.ensure((size_t)P.wf_nsamples * npx * 12));
@@ -791,8 +920,9 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
                 B.n_tiles = B.tiles_x * B.wf_tile_rows;
                 int chunks = (B.n_tiles + B.xcd_chunk - 1) / B.xcd_chunk;
                 B.grid_blocks = ((chunks + 7) / 8) * 8 * B.xcd_chunk;
-                int rc = run_wavefront_pass(s, s->ws[ln], lane_stream, B, count, lds_scene, walk, shard_px,
-                                            profile && smp == 0 && r0 == 0);
+                int rc = use_stream ? run_stream_pass(s, s->ws[ln], lane_stream, B, count, shard_px, profile && smp == 0 && r0 == 0)
+                                    : run_wavefront_pass(s, s->ws[ln], lane_stream, B, count, lds_scene, walk, shard_px,
+                                                         profile && smp == 0 && r0 == 0);
                 if (rc) return rc;
             }
         }
@@ -808,7 +938,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         HIP_TRY(hipEventRecord(s->ev_pick[1], s->stream));
         // a frame pushed onto another schedule by the workspace budget says the measured one is not available
         if (sched == measuring) s->pick.pending = sched;
-        else s->pick.ms[measuring] = 3.0e38f;
+        else if (measuring < 3) s->pick.ms[measuring] = 3.0e38f;
     }
     if (out->memory != 1) {
         // host planes hold res_y rows for a whole frame, p3d_local_rows() rows for a shard

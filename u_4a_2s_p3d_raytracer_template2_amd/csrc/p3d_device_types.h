@@ -16,7 +16,7 @@ namespace p3d {
 // One BVH2 inner node = both children's boxes + both child references: 64 B, four
 // dwordx4 loads, two slab tests per visit (2 x 32 algorithmic bytes).
 // child >= 0: inner node index.  child < 0: leaf.  As the builders emit it: ~child = (first_ref << 3) | (count - 1)
-// into a reference list; as uploaded (after type_leaves): ~child = index of a LeafRec.
+// into a reference list; as uploaded (after type_leaves): a leaf reference, see kLeaf* below.
 // An absent child has NaN bounds (every slab comparison is false).
 struct NodePair {
     float   lo0[3]; float hi0x;
@@ -26,9 +26,21 @@ struct NodePair {
 };
 static_assert(sizeof(NodePair) == 64, "NodePair must be 64 bytes");
 
+// The same node pair as scenes read from HBM get it: 32 B.  Per child three dwords, one per axis, of 16-bit plane
+// codes (lo | hi << 16; plane = q_base + code * q_scale, LaunchParams) and the child reference.  quantise_nodes()
+// (scene_flatten.cpp) rounds lo down and hi up and adds one code of margin, so the coded box contains the f32 one.
+struct QNode { uint32_t x0, y0, z0; int32_t child0; uint32_t x1, y1, z1; int32_t child1; };
+static_assert(sizeof(QNode) == 32, "QNode must be 32 bytes");
+
 // A leaf of the uploaded tree: three typed runs in primitive arrays stored in LEAF ORDER (scene_flatten.h:
-// type_leaves).  A node's child c < 0 is leaf ~c; leaf 0 is the empty leaf absent children point at.
+// type_leaves).  Leaf 0 is the empty leaf absent children point at.
 struct LeafRec { uint32_t tri_first, sph_first, box_first, counts; };         // counts: tris | spheres << 8 | boxes << 16
+// Leaf references as uploaded (bit 31 set).  Bits 30..29 say what the other bits are:
+//   3  ~reference = index of a LeafRec (the complement form: small indices have both bits set)
+//   1  a run of triangles, 2  a run of spheres: bits 28..25 = count - 1, bits 24..0 = first index in the leaf-ordered array
+//   0  never emitted (0x80000000 is the traversal's "done" marker)
+constexpr uint32_t kLeafKindShift = 29, kLeafCountShift = 25, kLeafFirstMask = (1u << 25) - 1u;
+constexpr uint32_t kLeafTris = 1, kLeafSpheres = 2, kLeafIndirect = 3;
 static_assert(sizeof(LeafRec) == 16, "LeafRec must be one quad");
 
 // primitive reference: kind in the top 2 bits, index into that kind's array below
@@ -58,6 +70,16 @@ struct RayRec { float o[3]; float ior; float d[3]; uint32_t link; };         // 
 struct NodeRec { float color[3]; float KR; float refl_ret[3]; uint32_t mat;
                  float refr_ret[3]; uint32_t link; };                        // 48 B
 constexpr uint32_t kLinkRefr = 0x80000000u;
+// ---- stream schedule records (traversal decoupled from shading, DESIGN.md §"Kernels")
+// What a closest-hit query returns: distance, primitive reference (kind << 30 | index; 0xFFFFFFFF = miss), scene
+// index and material of the hit -- the Hit of p3d_traverse.h as stored between the extend and the shade launches.
+struct HitRec { float t; uint32_t ref, sid, mat; };                          // 16 B
+// A queued shadow query: origin, direction and distance bound exactly as processLight() hands them to the
+// accelerator (normalised direction and len = |L| with an accelerator; the raw L and len < 0 = "no bound" without),
+// dst = light << 27 | index of the shaded ray in its shard's queue (its occlusion word gets bit `light`).
+struct ShadowJob { float o[3]; float len; float d[3]; uint32_t dst; };       // 32 B
+constexpr uint32_t kJobRayBits = 27, kJobRayMask = (1u << kJobRayBits) - 1u;
+constexpr uint32_t kStreamMaxLights = 32;
 
 struct DeviceCounters {
     unsigned long long closest_queries, shadow_queries, box_tests, sphere_tests, tri_tests,
@@ -73,6 +95,8 @@ struct LaunchParams {
     // small scene can be copied into LDS with one loop; wave-uniform arrays stay separate
     const void*        blob;
     uint32_t           blob_quads;
+    const QNode*       qnodes;            // quantised node pairs: what kernels that read the scene from HBM walk
+    float              q_scale[3], q_base[3];
     uint32_t           off_nodes, off_leaves, off_spheres, off_sphere_meta, off_tris, off_boxes, off_mats;
     int32_t            wg_waves;          // waves per workgroup of this launch (1, or 4 with an LDS scene)
     const PlaneRec*    planes;
@@ -130,6 +154,15 @@ struct LaunchParams {
     // = primitive refs (kind << 30 | index, planes kind 3) in scene order; nullptr until a GRID frame is asked for
     const uint32_t* grid_cells; const uint32_t* grid_items;
     int32_t grid_n[3]; float grid_min[3], grid_max[3];
+    // ---- stream schedule: extend launches (wf_extend_kernel) trace the queued rays of a level, shade launches consume
+    // the hit records.  xq_ctrl: block cursor of shard s at word 64 * s, zeroed by the shade launch after every extend launch.  Hit / occlusion records of level 1 are indexed tile * 64 + lane, of a deeper
+    // level shard * wf_cap_in + queue index; a shard's shadow queue holds xq_jcap jobs.
+    uint32_t*  xq_ctrl;
+    HitRec*    xq_hits;
+    uint32_t*  xq_occl;
+    ShadowJob* xq_jobs; uint32_t xq_jcap; uint32_t* xq_jcount;
+    int32_t    xq_refill;             // an extend wave fetches new rays once this many of its lanes are idle
+    int32_t    xq_min_blocks;         // ... and only ceil(blocks queued / xq_min_blocks) waves of an extend launch stay
     // ---- tile schedule (wf_tile_kernel): ONE launch per frame.  Persistent 256-thread workgroups draw
     // 16x16-pixel tiles from tw_ctrl[0] and run a tile's whole ray tree level by level among themselves;
     // every queue of a tile lives in the workgroup's private slot of the workspace (slot = blockIdx.x),

@@ -34,6 +34,8 @@ struct SceneOffsets { uint32_t nodes, leaves, spheres, sphere_meta, tris, boxes,
 
 struct GlobalScene {
     const float4* q; SceneOffsets o;
+    const uint4* qn;                  // quantised node pairs (QNode, p3d_device_types.h): two quads per node
+    float qs[3], qb[3];               // plane = qb + code * qs
     __device__ __forceinline__ float4 ld4(uint32_t i) const { return q[i]; }
     __device__ __forceinline__ uint32_t ld1(uint32_t quad, uint32_t dw) const {
         return reinterpret_cast<const uint32_t*>(q + quad)[dw];
@@ -50,16 +52,26 @@ struct LdsScene {
         return reinterpret_cast<const uint2*>(p3d_lds)[quad * 2 + pair];
     }
 };
-template <class SV> __device__ __forceinline__ void sv_node(const SV& sv, int32_t n, float4& q0, float4& q1, float4& q2, int4& q3) {
-    uint32_t b = sv.o.nodes + (uint32_t)n * 4u;
-    q0 = sv.ld4(b); q1 = sv.ld4(b + 1); q2 = sv.ld4(b + 2);
-    float4 t = sv.ld4(b + 3);
-    q3 = make_int4(__float_as_int(t.x), __float_as_int(t.y), __float_as_int(t.z), __float_as_int(t.w));
-}
 // a leaf = three typed ranges into the primitive arrays, which the host stores in LEAF ORDER (LeafRec):
-// x = first triangle, y = first sphere, z = first box, w = counts (triangles | spheres << 8 | boxes << 16)
-template <class SV> __device__ __forceinline__ uint4 sv_leaf(const SV& sv, uint32_t leaf) {
-    const float4 t = sv.ld4(sv.o.leaves + leaf);
+// x = first triangle, y = first sphere, z = first box, w = counts (triangles | spheres << 8 | boxes << 16).
+// `code` = a negative child reference (p3d_device_types.h: kLeaf*).  In scenes read from HBM a leaf that is one run of
+// triangles or of spheres -- nearly all of them -- is named by the reference itself: no record to fetch between the node
+// and its primitives (one dependent fetch less per leaf visit).  Mixed leaves and leaves with boxes go through their
+// LeafRec, and so does every leaf of a scene small enough for LDS (the host emits no direct references there: the
+// record is one LDS read, cheaper than decoding in kernels that are bound by instruction issue).
+__device__ __forceinline__ uint4 sv_leaf(const GlobalScene& sv, int32_t code) {
+    const uint32_t c = (uint32_t)code, kind = (c >> kLeafKindShift) & 3u;
+    uint4 L = make_uint4(c & kLeafFirstMask, c & kLeafFirstMask, 0u, 0u);
+    const uint32_t n = ((c >> kLeafCountShift) & 15u) + 1u;
+    L.w = kind == kLeafTris ? n : (n << 8);
+    if (kind == kLeafIndirect) {
+        const float4 t = sv.ld4(sv.o.leaves + ~c);
+        L = make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w));
+    }
+    return L;
+}
+__device__ __forceinline__ uint4 sv_leaf(const LdsScene& sv, int32_t code) {
+    const float4 t = sv.ld4(sv.o.leaves + ~(uint32_t)code);
     return make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w));
 }
 template <class SV> __device__ __forceinline__ float4 sv_sphere(const SV& sv, uint32_t i) { return sv.ld4(sv.o.spheres + i); }
@@ -163,12 +175,29 @@ template <> struct StackOf<GlobalScene> { typedef P3D_HBM_STACK type; };
 
 struct SlabRay { float kx, ky, kz, ix, iy, iz; };     // i = 1/d, k = -o/d: a plane's distance is fma(plane, i, k)
 
-__device__ __forceinline__ SlabRay make_slab(const Ray& r) {
+// 1 / d for the slab test.  A component that is zero (or denormal-small) is replaced by +-1e-30: with an INFINITE
+// reciprocal the fused form below gives NaN for one plane and an infinity for the other whenever the box spans the
+// coordinate origin on that axis, and a ray inside that slab was culled; with 1e30 both distances are finite (or
+// properly signed infinities) and the axis behaves like any other.
+__device__ __forceinline__ float slab_rcp(float d) {
+    return __builtin_amdgcn_rcpf(fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d);
+}
+// Scenes in LDS: f32 boxes, plane distance = fma(plane, i, -o * i)
+__device__ __forceinline__ SlabRay make_slab(const LdsScene&, const Ray& r) {
     SlabRay s;
     // 1-ulp hardware reciprocals are enough here: the slab test only has to be conservative
     // (boxes are padded by >= 1e-3, far above a relative 1e-7), it never decides a hit
-    s.ix = __builtin_amdgcn_rcpf(r.d.x); s.iy = __builtin_amdgcn_rcpf(r.d.y); s.iz = __builtin_amdgcn_rcpf(r.d.z);
+    s.ix = slab_rcp(r.d.x); s.iy = slab_rcp(r.d.y); s.iz = slab_rcp(r.d.z);
     s.kx = -r.o.x * s.ix; s.ky = -r.o.y * s.iy; s.kz = -r.o.z * s.iz;
+    return s;
+}
+// Scenes read from HBM: 16-bit plane codes, plane = qb + code * qs, so the distance is fma(code, qs * i, (qb - o) * i):
+// the same one FMA per plane, with the de-quantisation folded into the per-ray constants
+__device__ __forceinline__ SlabRay make_slab(const GlobalScene& g, const Ray& r) {
+    SlabRay s;
+    const float ix = slab_rcp(r.d.x), iy = slab_rcp(r.d.y), iz = slab_rcp(r.d.z);
+    s.ix = g.qs[0] * ix; s.iy = g.qs[1] * iy; s.iz = g.qs[2] * iz;
+    s.kx = (g.qb[0] - r.o.x) * ix; s.ky = (g.qb[1] - r.o.y) * iy; s.kz = (g.qb[2] - r.o.z) * iz;
     return s;
 }
 // conservative slab test against a padded box; returns entry distance in tn.  One fused multiply-add per plane
@@ -187,6 +216,29 @@ __device__ __forceinline__ bool slab(const SlabRay& s, float lx, float ly, float
     return (t0 <= t1) && (t1 >= 0.0f) && (t0 <= tlimit);
 }
 
+// One visit of node pair `n`: both children's slab tests (hit flags, entry distances) and their references.
+__device__ __forceinline__ void node_test(const LdsScene& sv, const SlabRay& s, int32_t n, float tlimit, bool& h0, bool& h1,
+                                          float& tn0, float& tn1, int32_t& c0, int32_t& c1) {
+    const uint32_t b = sv.o.nodes + (uint32_t)n * 4u;
+    const float4 q0 = sv.ld4(b), q1 = sv.ld4(b + 1), q2 = sv.ld4(b + 2), q3 = sv.ld4(b + 3);
+    h0 = slab(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tlimit, tn0);
+    h1 = slab(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tlimit, tn1);
+    c0 = __float_as_int(q3.x); c1 = __float_as_int(q3.y);
+}
+// 32-byte node pairs: per child three dwords of (lo | hi << 16) plane codes + the reference -- half the fetches of the
+// f32 node (these walks are bound by the L1-miss path, tools/ubench/gather_rate.hip), and two to four nodes of a
+// depth-first run share a cache line.  The codes convert exactly (integers < 2^16); the boxes only grew (host:
+// quantise_nodes), and the slab test only has to be conservative.
+__device__ __forceinline__ void node_test(const GlobalScene& sv, const SlabRay& s, int32_t n, float tlimit, bool& h0, bool& h1,
+                                          float& tn0, float& tn1, int32_t& c0, int32_t& c1) {
+    const uint4 a = sv.qn[(uint32_t)n * 2u], b = sv.qn[(uint32_t)n * 2u + 1u];
+    h0 = slab(s, (float)(a.x & 0xFFFFu), (float)(a.y & 0xFFFFu), (float)(a.z & 0xFFFFu),
+              (float)(a.x >> 16), (float)(a.y >> 16), (float)(a.z >> 16), tlimit, tn0);
+    h1 = slab(s, (float)(b.x & 0xFFFFu), (float)(b.y & 0xFFFFu), (float)(b.z & 0xFFFFu),
+              (float)(b.x >> 16), (float)(b.y >> 16), (float)(b.z >> 16), tlimit, tn1);
+    c0 = (int32_t)a.w; c1 = (int32_t)b.w;
+}
+
 // "t < closest_t" in scene order == nearest, lowest scene index on ties
 __device__ __forceinline__ void take_closer(Hit& best, bool h, float t, uint32_t ref, uint32_t sid, uint32_t mat) {
     if (h && (t < best.t || (t == best.t && sid < best.sid))) { best.t = t; best.ref = ref; best.sid = sid; best.mat = mat; }
@@ -198,7 +250,7 @@ __device__ __forceinline__ void take_closer(Hit& best, bool h, float t, uint32_t
 template <bool COUNT, class SV>
 __device__ __forceinline__ void leaf_closest(const LaunchParams& P, const SV& sv, const Ray& r, int32_t leaf,
                                              Hit& best, Ctr& ctr) {
-    const uint4 L = sv_leaf(sv, ~(uint32_t)leaf);
+    const uint4 L = sv_leaf(sv, leaf);
     const uint32_t nt = L.w & 0xFFu, ns = (L.w >> 8) & 0xFFu, nb = L.w >> 16;
     _Pragma("clang loop vectorize(disable) unroll(disable)")
     for (uint32_t i = 0; i < nt; i++) {
@@ -245,25 +297,22 @@ __device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const SV& sv, 
             }
         }
     }
-    SlabRay s = make_slab(r);
+    SlabRay s = make_slab(sv, r);
     typename StackOf<SV>::type st(region);
     int32_t cur = 0;
     while (cur != P3D_DONE) {
         while (cur >= 0) {
-            float4 q0, q1, q2; int4 q3;
-            sv_node(sv, cur, q0, q1, q2, q3);
-            float tn0, tn1;
-            bool h0 = slab(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best.t, tn0);
-            bool h1 = slab(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best.t, tn1);
+            float tn0, tn1; bool h0, h1; int32_t c0, c1;
+            node_test(sv, s, cur, best.t, h0, h1, tn0, tn1, c0, c1);
             if (COUNT) ctr.box += 2;
             if (h0 && h1) {
                 bool swap = tn1 < tn0;
-                int32_t nearc = swap ? q3.y : q3.x, farc = swap ? q3.x : q3.y;
+                int32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
                 float fart = swap ? tn0 : tn1;
                 st.push(farc, fart);
                 cur = nearc;
-            } else if (h0) cur = q3.x;
-            else if (h1) cur = q3.y;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
             else if (!st.pop(best.t, cur)) cur = P3D_DONE;
         }
         if (cur != P3D_DONE) {
@@ -279,7 +328,7 @@ __device__ __forceinline__ Hit closest_hit(const LaunchParams& P, const SV& sv, 
 template <bool COUNT, class SV>
 __device__ __forceinline__ bool leaf_any(const LaunchParams& P, const SV& sv, const Ray& r, int32_t leaf, bool bounded,
                                          float tmax, Ctr& ctr) {
-    const uint4 L = sv_leaf(sv, ~(uint32_t)leaf);
+    const uint4 L = sv_leaf(sv, leaf);
     const uint32_t nt = L.w & 0xFFu, ns = (L.w >> 8) & 0xFFu, nb = L.w >> 16;
     bool occluded = false;
     _Pragma("clang loop vectorize(disable) unroll(disable)")
@@ -328,24 +377,21 @@ __device__ __forceinline__ bool any_hit(const LaunchParams& P, const SV& sv, con
             }
         }
     }
-    SlabRay s = make_slab(r);
+    SlabRay s = make_slab(sv, r);
     float tlimit = bounded ? tmax : 3.402823466e+38f;
     typename StackOf<SV>::type st(region);
     int32_t cur = 0;
     while (cur != P3D_DONE) {
         while (cur >= 0) {
-            float4 q0, q1, q2; int4 q3;
-            sv_node(sv, cur, q0, q1, q2, q3);
-            float tn0, tn1;
-            bool h0 = slab(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tlimit, tn0);
-            bool h1 = slab(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tlimit, tn1);
+            float tn0, tn1; bool h0, h1; int32_t c0, c1;
+            node_test(sv, s, cur, tlimit, h0, h1, tn0, tn1, c0, c1);
             if (COUNT) ctr.box += 2;
             if (h0 && h1) {
                 bool swap = tn1 < tn0;
-                st.push(swap ? q3.x : q3.y, 0.0f);
-                cur = swap ? q3.y : q3.x;
-            } else if (h0) cur = q3.x;
-            else if (h1) cur = q3.y;
+                st.push(swap ? c0 : c1, 0.0f);
+                cur = swap ? c1 : c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
             else if (!st.pop(cur)) cur = P3D_DONE;
         }
         if (cur != P3D_DONE) {
@@ -514,7 +560,7 @@ __device__ __forceinline__ void leaf_closest_packet(const LaunchParams& P, const
                                                     int32_t leaf, Hit& best, Ctr& ctr) {
     // the leaf is wave-uniform: its record and its primitives are fetched once for the wave (same address in
     // every lane: a broadcast LDS read or one cache line), the counts are scalar loop bounds
-    const uint4 Lv = sv_leaf(sv, ~(uint32_t)leaf);
+    const uint4 Lv = sv_leaf(sv, leaf);
     const uint32_t tri0 = __builtin_amdgcn_readfirstlane(Lv.x), sph0 = __builtin_amdgcn_readfirstlane(Lv.y),
                    box0 = __builtin_amdgcn_readfirstlane(Lv.z), cnt = __builtin_amdgcn_readfirstlane(Lv.w);
     const uint32_t nt = cnt & 0xFFu, ns = (cnt >> 8) & 0xFFu, nb = cnt >> 16;
@@ -571,18 +617,16 @@ __device__ __forceinline__ Hit closest_hit_packet(const LaunchParams& P, const S
         }
     }
     if (__ballot(active) == 0) return best;
-    SlabRay s = make_slab(r);
+    SlabRay s = make_slab(sv, r);
     int sp = 0;
     int32_t cur = 0;
     for (;;) {
-        float4 q0, q1, q2; int4 q3;
-        sv_node(sv, cur, q0, q1, q2, q3);
-        float tn0 = 0.0f, tn1 = 0.0f;
-        const bool h0 = active && slab(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best.t, tn0);
-        const bool h1 = active && slab(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best.t, tn1);
+        float tn0 = 0.0f, tn1 = 0.0f; bool t0, t1; int32_t cv0, cv1;
+        node_test(sv, s, cur, best.t, t0, t1, tn0, tn1, cv0, cv1);
+        const bool h0 = active && t0, h1 = active && t1;
         if (COUNT && active) ctr.box += 2;
         uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
-        const int32_t c0 = __builtin_amdgcn_readfirstlane(q3.x), c1 = __builtin_amdgcn_readfirstlane(q3.y);
+        const int32_t c0 = __builtin_amdgcn_readfirstlane(cv0), c1 = __builtin_amdgcn_readfirstlane(cv1);
         if (m0 && c0 < 0) { leaf_closest_packet<COUNT>(P, sv, r, h0, c0, best, ctr); m0 = 0; }
         if (m1 && c1 < 0) { leaf_closest_packet<COUNT>(P, sv, r, h1, c1, best, ctr); m1 = 0; }
         if (m0 && m1) {
@@ -620,26 +664,24 @@ __device__ __forceinline__ bool any_hit_packet(const LaunchParams& P, const SV& 
         }
     }
     if (__ballot(active && !occ) == 0) return occ;
-    SlabRay s = make_slab(r);
+    SlabRay s = make_slab(sv, r);
     const float tlimit = bounded ? tmax : 3.402823466e+38f;
     int sp = 0;
     int32_t cur = 0;
     for (;;) {
-        float4 q0, q1, q2; int4 q3;
-        sv_node(sv, cur, q0, q1, q2, q3);
-        float tn0, tn1;
+        float tn0, tn1; bool t0, t1; int32_t cv0, cv1;
         const bool live = active && !occ;
-        const bool h0 = live && slab(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tlimit, tn0);
-        const bool h1 = live && slab(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tlimit, tn1);
+        node_test(sv, s, cur, tlimit, t0, t1, tn0, tn1, cv0, cv1);
+        const bool h0 = live && t0, h1 = live && t1;
         if (COUNT && live) ctr.box += 2;
         uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
-        const int32_t c0 = __builtin_amdgcn_readfirstlane(q3.x), c1 = __builtin_amdgcn_readfirstlane(q3.y);
+        const int32_t c0 = __builtin_amdgcn_readfirstlane(cv0), c1 = __builtin_amdgcn_readfirstlane(cv1);
         for (int side = 0; side < 2; side++) {
             const int32_t c = side ? c1 : c0;
             const uint64_t m = side ? m1 : m0;
             if (!(m && c < 0)) continue;
             const bool hl = (side ? h1 : h0) && !occ;
-            const uint4 Lv = sv_leaf(sv, ~(uint32_t)c);
+            const uint4 Lv = sv_leaf(sv, c);
             const uint32_t tri0 = __builtin_amdgcn_readfirstlane(Lv.x), sph0 = __builtin_amdgcn_readfirstlane(Lv.y),
                            box0 = __builtin_amdgcn_readfirstlane(Lv.z), cnt = __builtin_amdgcn_readfirstlane(Lv.w);
             const uint32_t nt = cnt & 0xFFu, ns = (cnt >> 8) & 0xFFu, nb = cnt >> 16;

@@ -95,7 +95,7 @@ std::string flatten_scene(const p3d_scene_desc& d, FlatScene& F) {
     return std::string();
 }
 
-void type_leaves(std::vector<NodePair>& nodes, const std::vector<uint32_t>& refs, FlatScene& F, TypedLeaves& T) {
+void type_leaves(std::vector<NodePair>& nodes, const std::vector<uint32_t>& refs, FlatScene& F, TypedLeaves& T, bool direct) {
     const uint32_t kNone = 0xFFFFFFFFu;
     T.leaves.clear();
     T.leaves.push_back(LeafRec{0, 0, 0, 0});                      // leaf 0: empty
@@ -115,6 +115,14 @@ void type_leaves(std::vector<NodePair>& nodes, const std::vector<uint32_t>& refs
             else { T.map_box[idx] = (uint32_t)box.size(); box.push_back(F.boxes[idx]); nb++; }
         }
         L.counts = nt | (ns << 8) | (nb << 16);
+        if (direct && nb == 0 && (nt == 0) != (ns == 0)) {        // one run of one type: the reference names it
+            const uint32_t run_first = nt ? L.tri_first : L.sph_first, run = nt ? nt : ns;
+            if (run_first <= kLeafFirstMask && run <= 16u) {
+                child = (int32_t)(0x80000000u | ((nt ? kLeafTris : kLeafSpheres) << kLeafKindShift) | ((run - 1u) << kLeafCountShift) | run_first);
+                return;
+            }
+        }
+        if (T.leaves.size() >= (1u << kLeafKindShift)) { T.overflow = true; return; }   // (2^29 mixed leaves: never in practice)
         child = ~(int32_t)T.leaves.size();
         T.leaves.push_back(L);
     };
@@ -127,6 +135,48 @@ void type_leaves(std::vector<NodePair>& nodes, const std::vector<uint32_t>& refs
     for (size_t i = 0; i < F.boxes.size(); i++)
         if (T.map_box[i] == kNone) { T.map_box[i] = (uint32_t)box.size(); box.push_back(F.boxes[i]); }
     F.spheres.swap(sph); F.sphere_meta.swap(sph_meta); F.tris.swap(tri); F.boxes.swap(box);
+}
+
+void quantise_nodes(const std::vector<NodePair>& nodes, QuantisedNodes& Q) {
+    auto child_box = [](const NodePair& n, int c, float lo[3], float hi[3]) {
+        if (c == 0) { lo[0] = n.lo0[0]; lo[1] = n.lo0[1]; lo[2] = n.lo0[2]; hi[0] = n.hi0x; hi[1] = n.hi0yz[0]; hi[2] = n.hi0yz[1]; }
+        else { lo[0] = n.lo1xy[0]; lo[1] = n.lo1xy[1]; lo[2] = n.lo1z; hi[0] = n.hi1[0]; hi[1] = n.hi1[1]; hi[2] = n.hi1[2]; }
+    };
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (const NodePair& n : nodes)
+        for (int c = 0; c < 2; c++) {
+            float lo[3], hi[3];
+            child_box(n, c, lo, hi);
+            if (!(lo[0] <= hi[0])) continue;                       // absent child (NaN bounds)
+            for (int a = 0; a < 3; a++) { mn[a] = std::min<double>(mn[a], lo[a]); mx[a] = std::max<double>(mx[a], hi[a]); }
+        }
+    for (int a = 0; a < 3; a++) {
+        if (mn[a] > mx[a]) { mn[a] = 0.0; mx[a] = 1.0; }           // no box at all
+        // all boxes land in codes [2, 65533]: room for the one-code margin without clamping
+        const double ext = std::max(mx[a] - mn[a], 1e-6 * std::max({std::fabs(mn[a]), std::fabs(mx[a]), 1.0}));
+        Q.scale[a] = (float)(ext / 65530.0);
+        if (!(Q.scale[a] > 0.0f)) Q.scale[a] = 1e-30f;
+        Q.base[a] = (float)(mn[a] - 2.5 * (double)Q.scale[a]);
+    }
+    Q.nodes.resize(nodes.size());
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const NodePair& n = nodes[i];
+        uint32_t code[2][3];
+        for (int c = 0; c < 2; c++) {
+            float lo[3], hi[3];
+            child_box(n, c, lo, hi);
+            for (int a = 0; a < 3; a++) {
+                if (!(lo[0] <= hi[0])) { code[c][a] = 0u; continue; }
+                const double b = Q.base[a], sc = Q.scale[a];
+                double ql = std::floor(((double)lo[a] - b) / sc) - 1.0, qh = std::ceil(((double)hi[a] - b) / sc) + 1.0;
+                ql = std::min(std::max(ql, 0.0), 65535.0); qh = std::min(std::max(qh, 0.0), 65535.0);
+                code[c][a] = (uint32_t)ql | ((uint32_t)qh << 16);
+            }
+        }
+        QNode& q = Q.nodes[i];
+        q.x0 = code[0][0]; q.y0 = code[0][1]; q.z0 = code[0][2]; q.child0 = n.child0;
+        q.x1 = code[1][0]; q.y1 = code[1][1]; q.z1 = code[1][2]; q.child1 = n.child1;
+    }
 }
 
 }  // namespace p3d

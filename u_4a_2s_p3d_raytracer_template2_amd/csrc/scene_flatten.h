@@ -32,8 +32,18 @@ std::string flatten_scene(const p3d_scene_desc& d, FlatScene& out);
 struct TypedLeaves {
     std::vector<LeafRec> leaves;
     std::vector<uint32_t> map_sph, map_tri, map_box;
+    bool overflow = false;            // more leaf records than a reference can index
 };
-void type_leaves(std::vector<NodePair>& nodes, const std::vector<uint32_t>& refs, FlatScene& F, TypedLeaves& out);
+// direct: single-type leaves are named by their reference (kLeafTris / kLeafSpheres) instead of getting a LeafRec
+void type_leaves(std::vector<NodePair>& nodes, const std::vector<uint32_t>& refs, FlatScene& F, TypedLeaves& out, bool direct);
+
+// 32-byte node pairs for scenes read from HBM (QNode): 16-bit plane codes on a grid over the boxes of all nodes,
+// plane = base + code * scale per axis.  Every coded box contains its f32 box with one code of margin on each side
+// (lo: floor - 1, hi: ceil + 1, evaluated in double against the f32 base / scale the device uses), so a slab test on the
+// coded box is conservative wherever one on the f32 box was.  An absent child (NaN box) becomes the point box at
+// code 0, outside every real box; its reference is the empty leaf.
+struct QuantisedNodes { std::vector<QNode> nodes; float scale[3], base[3]; };
+void quantise_nodes(const std::vector<NodePair>& nodes, QuantisedNodes& out);
 
 }  // namespace p3d
 #endif
