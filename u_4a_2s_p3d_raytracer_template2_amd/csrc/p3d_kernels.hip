@@ -885,10 +885,14 @@ __global__ __launch_bounds__(64) void wf_shade_kernel(const LaunchParams P) {
 }
 
 // ------------------------------------------------------------------ TREE schedule
-// shade-stack frame in LDS: 12 dwords, [field][lane]
+// shade-stack frame: 12 dwords.  STRIDE 64: in LDS, [field][lane] (scenes rendered from an LDS copy, and trees deeper
+// than 8 levels).  STRIDE 1: in the lane's PRIVATE memory (scratch) -- scenes read from HBM are bound by how many waves
+// are resident to hide fetch latency, frames are touched once per tree node, and 9 KB of LDS per wave for three of them
+// held the dragon to 10 waves per CU: 1.81 -> 1.55 ms with the frames in scratch (16-25 waves per CU).
+template <int STRIDE>
 struct Frames {
-    uint32_t* base;   // this lane's field-0 of frame-0; field stride 64, frame stride 12*64
-    __device__ __forceinline__ uint32_t& f(int frame, int field) { return base[(frame * 12 + field) * 64]; }
+    uint32_t* base;   // this lane's field-0 of frame-0; field stride STRIDE, frame stride 12 * STRIDE
+    __device__ __forceinline__ uint32_t& f(int frame, int field) { return base[(frame * 12 + field) * STRIDE]; }
     __device__ __forceinline__ void put3(int frame, int field, V3 v) {
         f(frame, field) = __float_as_uint(v.x); f(frame, field + 1) = __float_as_uint(v.y);
         f(frame, field + 2) = __float_as_uint(v.z);
@@ -905,8 +909,8 @@ enum { FR_C = 0, FR_KR = 3, FR_META = 4, FR_A = 5, FR_RD = 8, FR_IOR = 11 };
 #define FR_WAIT_REFR 0x80000000u
 
 // One primary ray's whole tree: rayTracing(ray, 1, 1.0) of RT/main.cpp:530-721, iterative.
-template <bool COUNT, bool GRID, class SV>
-__device__ __forceinline__ V3 trace_tree(const LaunchParams& P, const SV& sv, Ray ray, const TravCtx& tc, Frames fr,
+template <bool COUNT, bool GRID, class SV, class FR>
+__device__ __forceinline__ V3 trace_tree(const LaunchParams& P, const SV& sv, Ray ray, const TravCtx& tc, FR fr,
                                          int32_t& primary_hit, Ctr& ctr) {
     int fsp = 0;              // frames on the stack == depth - 1
     float ior_1 = 1.0f;
@@ -966,16 +970,19 @@ __device__ __forceinline__ V3 trace_tree(const LaunchParams& P, const SV& sv, Ra
     }
 }
 
-template <bool COUNT, bool LDS, int OCC, bool GRID = false>
+// PRIV = dwords of private memory for the frames (12 per level below the first), 0 = frames in LDS
+template <bool COUNT, bool LDS, int OCC, bool GRID = false, int PRIV = 0>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kernel(const LaunchParams P) {
     const typename View<LDS>::type sv = View<LDS>::make(P);
     const int lane = threadIdx.x & 63;
     int x, y, row;
     if (!tile_pixel(P, x, y, row)) return;               // no barriers below: early exit is safe
-    const uint32_t frame_dwords = (uint32_t)(P.max_depth > 1 ? (P.max_depth - 1) : 1) * 12 * 64;
+    uint32_t priv[PRIV > 0 ? PRIV : 1];
     uint32_t* wbase;
+    const uint32_t frame_dwords = PRIV > 0 ? 0u : (uint32_t)(P.max_depth > 1 ? (P.max_depth - 1) : 1) * 12 * 64;
     const TravCtx st = wave_stack<LDS>(P, frame_dwords, &wbase);
-    Frames fr; fr.base = wbase + P.trav_stack_dwords + lane;
+    Frames<(PRIV > 0) ? 1 : 64> fr;
+    if constexpr (PRIV > 0) fr.base = priv; else fr.base = wbase + P.trav_stack_dwords + lane;
 
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
     V3 color = mk(0.0f, 0.0f, 0.0f);
@@ -1074,7 +1081,13 @@ __global__ void debug_intersect_kernel(uint32_t n, const uint32_t* type, const f
 
 // ------------------------------------------------------------------ launchers (host)
 static size_t scene_lds_bytes(const LaunchParams& P, bool lds) { return lds ? (size_t)P.blob_quads * 16 : 0; }
+// frames of the tree kernel: private memory for scenes read from HBM up to depth 8, LDS otherwise
+static int tree_private_dwords(const LaunchParams& P, bool lds) {
+    if (lds || P.accel == 1) return 0;
+    return P.max_depth <= 4 ? 36 : (P.max_depth <= 8 ? 84 : 0);
+}
 size_t tree_kernel_lds_bytes(const LaunchParams& P, bool lds) {
+    if (tree_private_dwords(P, lds)) return scene_lds_bytes(P, lds) + (size_t)P.trav_stack_dwords * 4 * P.wg_waves;
     int frames = P.max_depth > 1 ? (P.max_depth - 1) : 1;
     size_t wave_dwords = (size_t)P.trav_stack_dwords + (size_t)frames * 12 * 64;
     return scene_lds_bytes(P, lds) + wave_dwords * 4 * P.wg_waves;
@@ -1111,9 +1124,19 @@ P3D_DEFINE_SELECTOR(wf_secondary_fn, wf_secondary_kernel)
 P3D_DEFINE_SELECTOR(wf_tile_fn, wf_tile_kernel)
 #undef P3D_DEFINE_SELECTOR
 
-static const void* tree_fn(bool count, bool lds, int occ, bool grid) {
+static const void* tree_fn(bool count, bool lds, int occ, bool grid, int priv = 0) {
     if (grid) return count ? (lds ? fn_ptr(whitted_tree_kernel<true, true, 1, true>) : fn_ptr(whitted_tree_kernel<true, false, 1, true>))
                            : (lds ? fn_ptr(whitted_tree_kernel<false, true, 1, true>) : fn_ptr(whitted_tree_kernel<false, false, 1, true>));
+    if (!lds && priv == 36) {
+        if (count) return fn_ptr(whitted_tree_kernel<true, false, 1, false, 36>);
+        return occ == 5 ? fn_ptr(whitted_tree_kernel<false, false, 5, false, 36>) : occ == 6 ? fn_ptr(whitted_tree_kernel<false, false, 6, false, 36>)
+                                                                                           : fn_ptr(whitted_tree_kernel<false, false, 1, false, 36>);
+    }
+    if (!lds && priv == 84) {
+        if (count) return fn_ptr(whitted_tree_kernel<true, false, 1, false, 84>);
+        return occ == 5 ? fn_ptr(whitted_tree_kernel<false, false, 5, false, 84>) : occ == 6 ? fn_ptr(whitted_tree_kernel<false, false, 6, false, 84>)
+                                                                                           : fn_ptr(whitted_tree_kernel<false, false, 1, false, 84>);
+    }
     if (count) return lds ? fn_ptr(whitted_tree_kernel<true, true, 1>) : fn_ptr(whitted_tree_kernel<true, false, 1>);
     if (occ == 5) return lds ? fn_ptr(whitted_tree_kernel<false, true, 5>) : fn_ptr(whitted_tree_kernel<false, false, 5>);
     if (occ == 6) return lds ? fn_ptr(whitted_tree_kernel<false, true, 6>) : fn_ptr(whitted_tree_kernel<false, false, 6>);
@@ -1126,8 +1149,8 @@ static hipError_t launch_by_pointer(const void* fn, const LaunchParams& P, dim3 
 }
 
 hipError_t launch_tree(const LaunchParams& P, bool count, bool lds, int occ, hipStream_t stream) {
-    return launch_by_pointer(tree_fn(count, lds, occ, P.accel == 1), P, dim3((unsigned)P.grid_blocks), dim3(64 * P.wg_waves),
-                             tree_kernel_lds_bytes(P, lds), stream);
+    return launch_by_pointer(tree_fn(count, lds, occ, P.accel == 1, tree_private_dwords(P, lds)), P, dim3((unsigned)P.grid_blocks),
+                             dim3(64 * P.wg_waves), tree_kernel_lds_bytes(P, lds), stream);
 }
 hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, int walk, int occ, hipStream_t stream) {
     return launch_by_pointer(wf_primary_fn(count, lds, walk, occ, P.features != 0), P, dim3((unsigned)P.grid_blocks),
