@@ -68,3 +68,31 @@ def test_deep_trees_fall_back_to_the_tree_kernel_when_the_queues_do_not_fit(tmp_
     sc = O.Scene(path)
     ref = sc.render(max_depth=10, accel=2)
     assert np.array_equal(a["hit_id"], ref["hit_id"]) and np.abs(a["rgb32f"] - ref["rgb32f"]).max() <= 1e-4
+
+
+def test_rays_with_a_zero_direction_component(tmp_path):
+    """A camera looking straight down an axis at an odd resolution: the centre column's rays have d.x == 0 exactly
+    (and the centre pixel d.x == d.y == 0) while the eye's x is not 0 and the scene's boxes span x == 0 -- the case
+    in which an infinite slab reciprocal turned 'inside the slab' into NaN / -inf and culled the box.  Both node
+    formats (f32 nodes from LDS, quantised nodes from HBM), every schedule."""
+    rng = np.random.default_rng(5)
+    L = ["accel 2", "spp 0", "bclr 0.1 0.3 0.6", "v", "from 0.5 0.25 6", "at 0.5 0.25 0", "up 0 1 0", "angle 40",
+         "hither 0.01", "resolution 65 33", "aperture 0", "focal 1", "l 3 4 8 1 1 1", "l 0.5 0.25 9 0.6 0.6 0.6"]
+    for _ in range(14):
+        L.append("f %.3f %.3f %.3f 0.7 1 1 1 %.2f 40 0 1" % (*rng.uniform(0.2, 1, 3), rng.uniform(0, 0.6)))
+        L.append("s %.4f %.4f %.4f %.4f" % (*rng.uniform(-1.2, 1.2, 3), rng.uniform(0.2, 0.5)))
+    for _ in range(6):
+        L.append("f %.3f %.3f %.3f 0.8 1 1 1 0.3 60 0 1" % tuple(rng.uniform(0.2, 1, 3)))
+        a = rng.uniform(-1.5, 1.5, 3)
+        L.append("p 3\n%.4f %.4f %.4f\n%.4f %.4f %.4f\n%.4f %.4f %.4f" % (*a, *(a + rng.uniform(-1, 1, 3)), *(a + rng.uniform(-1, 1, 3))))
+    L.append("f 0.5 0.5 0.9 0.8 1 1 1 0.2 30 0 1")
+    L.append("box -0.4 -0.3 -0.2 0.9 0.8 0.4")
+    path = str(tmp_path / "axis.p3f")
+    open(path, "w").write("\n".join(L) + "\n")
+    hs = P.HostScene(path)
+    cam = hs.camera()
+    assert cam.u[1] == 0 and cam.u[2] == 0 and cam.n[0] == 0 and cam.n[1] == 0       # the set-up really is axis-parallel
+    for kw in (dict(wavefront=True), dict(tile=True), dict(tree=True), dict(wavefront=True, no_lds=True),
+               dict(tree=True, no_lds=True), dict(stream=True, no_lds=True), dict(wavefront=True, packet=True)):
+        check(path, 2, 4, **kw)
+    check(path, 0, 3, wavefront=True, no_lds=True)

@@ -175,12 +175,16 @@ template <> struct StackOf<GlobalScene> { typedef P3D_HBM_STACK type; };
 
 struct SlabRay { float kx, ky, kz, ix, iy, iz; };     // i = 1/d, k = -o/d: a plane's distance is fma(plane, i, k)
 
-// 1 / d for the slab test.  A component that is zero (or denormal-small) is replaced by +-1e-30: with an INFINITE
-// reciprocal the fused form below gives NaN for one plane and an infinity for the other whenever the box spans the
-// coordinate origin on that axis, and a ray inside that slab was culled; with 1e30 both distances are finite (or
-// properly signed infinities) and the axis behaves like any other.
+// 1 / d for the slab test, clamped to +-1e30 (one v_med3).  With an INFINITE reciprocal (d == 0) the fused form below
+// gives NaN for one plane and an infinity for the other whenever the box spans the coordinate origin on that axis, and
+// a ray inside that slab was culled; with 1e30 both distances are finite (or properly signed infinities) and the axis
+// behaves like any other: the slab's two distances keep their signs, and their size is far beyond any hit distance.
 __device__ __forceinline__ float slab_rcp(float d) {
-    return __builtin_amdgcn_rcpf(fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d);
+#ifdef P3D_SLAB_RCP_UNCLAMPED       // (diagnostic build: shows tests/test_gpu_random_scenes.py::test_rays_with_a_zero_direction_component failing)
+    return __builtin_amdgcn_rcpf(d);
+#else
+    return __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d), -1e30f, 1e30f);
+#endif
 }
 // Scenes in LDS: f32 boxes, plane distance = fma(plane, i, -o * i)
 __device__ __forceinline__ SlabRay make_slab(const LdsScene&, const Ray& r) {
