@@ -138,10 +138,6 @@ typedef struct p3d_render_params {
                                     run a tile's whole ray tree level by level among themselves (queues in a
                                     private workspace slot, counters in LDS, no global atomics between levels)  */
 #define P3D_FLAG_WAVEFRONT 32u   /* one launch per tree level over the whole frame + resolve launches          */
-#define P3D_FLAG_STREAM_KERNELS 512u /* the wavefront schedule with traversal in launches of its own: persistent waves
-                                    trace the queued rays of a level and refill lanes whose walk has ended, separate
-                                    launches shade the hit records (scenes read from HBM, accel NONE / BVH, <= 32
-                                    lights; P3D_ERR_ARG otherwise)                                                */
 #define P3D_FLAG_DEVICE_SAMPLES 128u /* p3d_render_params::samples is a DEVICE pointer on the scene's device (same
                                     layout): the caller uploaded the sample array once instead of per call    */
 #define P3D_FLAG_PROFILE 16u     /* bracket the frame and its dominant kernel (the level-1 /
@@ -231,8 +227,7 @@ int p3d_set_tuning(p3d_scene* scene, int32_t xcd_chunk, int32_t workspace_mib, i
 int p3d_get_profile(p3d_scene* scene, float* frame_ms, float* kernel_ms);
 
 /* Kernel schedule the most recent p3d_render() of this scene used: 0 = wavefront (level kernels),
- * 1 = tree (one launch, per-lane stacks), 2 = tile (one launch, per-tile levels), 3 = stream (extend + shade
- * launches per level). P3D_ERR_STATE before the
+ * 1 = tree (one launch, per-lane stacks), 2 = tile (one launch, per-tile levels). P3D_ERR_STATE before the
  * first render. */
 int p3d_last_schedule(p3d_scene* scene, int32_t* schedule);
 

@@ -114,30 +114,6 @@ def test_frame_matches_golden_fixture(frames, name, schedule):
     assert c["pixels"] == m["res"][0] * m["res"][1]
 
 
-@pytest.mark.parametrize("name", sorted(n for n in CASES if CASES[n]["accel"] != 1))
-def test_stream_schedule_matches_golden_fixture(frames, name):
-    """The opt-in stream schedule (traversal in persistent extend launches, shading in launches of its own; scenes
-    read from HBM, accel NONE / BVH): same bits and ray counts as the reference's frames."""
-    m = CASES[name]
-    out = gpu_render(m, counters=True, stream=True, no_lds=True)
-    compare(out, frames[name + "/rgb8"], frames[name + "/rgb32f"], frames[name + "/hit_id"], name)
-    c = out["counters"]
-    assert c["closest_queries"] == m["counters"]["closest_queries"], name
-    assert c["shadow_queries"] == m["counters"]["shadow_queries"], name
-    assert c["pixels"] == m["res"][0] * m["res"][1]
-
-
-def test_stream_schedule_is_refused_where_it_cannot_run():
-    m = CASES["c2_mount_low_256x144_d4_bvh"]
-    hs = P.HostScene(scene_path(m["scene"])); hs.set_resolution(*m["res"])
-    ds = P.DeviceScene.from_host(hs)
-    with pytest.raises(RuntimeError):
-        ds.render(hs.camera(), accel=2, stream=True)             # scene served from LDS
-    with pytest.raises(RuntimeError):
-        ds.render(hs.camera(), accel=1, stream=True, no_lds=True)   # GRID mode walks the reference's grid
-    ds.close()
-
-
 @pytest.mark.parametrize("leaf_max", [1, 2, 8])
 def test_result_is_independent_of_the_bvh_shape(frames, leaf_max):
     for name in ("c2_mount_low_256x144_d4_bvh", "balls_box_128_d4_none", "c3_dragon_96_d4_bvh"):

@@ -93,6 +93,6 @@ def test_rays_with_a_zero_direction_component(tmp_path):
     cam = hs.camera()
     assert cam.u[1] == 0 and cam.u[2] == 0 and cam.n[0] == 0 and cam.n[1] == 0       # the set-up really is axis-parallel
     for kw in (dict(wavefront=True), dict(tile=True), dict(tree=True), dict(wavefront=True, no_lds=True),
-               dict(tree=True, no_lds=True), dict(stream=True, no_lds=True), dict(wavefront=True, packet=True)):
+               dict(tree=True, no_lds=True), dict(tile=True, no_lds=True), dict(wavefront=True, packet=True)):
         check(path, 2, 4, **kw)
     check(path, 0, 3, wavefront=True, no_lds=True)

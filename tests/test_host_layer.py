@@ -231,6 +231,36 @@ def test_bvh_builder_invariants(name, leaf_max):
     assert max_depth <= b["max_depth"] + 1 <= 64
 
 
+@pytest.mark.parametrize("name", ["mount_low", "balls_box", "mount_high", "dragon"])
+def test_quantised_nodes_contain_the_f32_boxes(name):
+    """Scenes read from HBM walk 32-byte node pairs of 16-bit plane codes (plane = base + code * scale).  Every coded
+    box must contain the builder's padded f32 box with a full code of margin on each side -- evaluated here in the f32
+    arithmetic of the kernel's de-quantisation -- keep the child references, and code absent children as the point 0."""
+    hs = P.HostScene(scene_path(name))
+    b = P.host_bvh(hs.desc(), 0)
+    f = b["nodes"].view(np.float32)
+    q, sc, ba = b["qnodes"], b["qscale"], b["qbase"]
+    assert q.shape == (len(f), 8) and (sc > 0).all()
+    lo = np.stack([f[:, 0:3], np.stack([f[:, 6], f[:, 7], f[:, 8]], 1)], 1)               # [node, child, axis]
+    hi = np.stack([np.stack([f[:, 3], f[:, 4], f[:, 5]], 1), f[:, 9:12]], 1)
+    code = np.stack([q[:, 0:3], q[:, 4:7]], 1)
+    qlo, qhi = (code & 0xFFFF).astype(np.float32), (code >> 16).astype(np.float32)
+    absent = np.isnan(lo[:, :, 0])
+    assert (code[absent] == 0).all()
+    real = ~absent
+    # a full code of margin on each side: exact in double, >= 0.99 of a code when evaluated in float32
+    d64 = ba.astype(np.float64), sc.astype(np.float64)
+    assert ((d64[0] + (qlo.astype(np.float64) + 1) * d64[1])[real] <= lo[real]).all()
+    assert ((d64[0] + (qhi.astype(np.float64) - 1) * d64[1])[real] >= hi[real]).all()
+    dlo = (ba + qlo * sc).astype(np.float32)[real]
+    dhi = (ba + qhi * sc).astype(np.float32)[real]
+    assert ((lo[real] - dlo) >= 0.99 * sc).all() and ((dhi - hi[real]) >= 0.99 * sc).all()
+    assert (qlo[real] >= 1).all() and (qhi[real] <= 65534).all() and (qlo[real] < qhi[real]).all()
+    # not looser than three codes per side
+    assert ((lo[real] - (ba + qlo[real] * sc)) <= 3.01 * sc).all() and (((ba + qhi[real] * sc) - hi[real]) <= 3.01 * sc).all()
+    assert np.array_equal(q[:, 3], b["nodes"][:, 12]) and np.array_equal(q[:, 7], b["nodes"][:, 13])
+
+
 def test_local_rows():
     assert P.local_rows(1080, 16, 1) == 1088
     assert P.local_rows(1080, 16, 8) == 144      # 68 blocks -> 9 per rank

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Stream schedule against the other schedules: same bits, same counters, time per frame (GPU box tool).
-usage: python tools/stream_probe.py [--quick]"""
+"""Every schedule on scenes read from HBM: same bits, same counters, time per frame (GPU box tool).
+usage: python tools/schedule_probe.py [--quick]"""
 import os
 import sys
 import time
@@ -34,7 +34,7 @@ for name, w, h, depth, accel in cases:
         cam = hs.camera()
         ds = P.DeviceScene.from_host(hs)
     ref = None
-    for sched in ("tile", "wavefront", "tree", "stream"):
+    for sched in ("tile", "wavefront", "tree"):
         kw = dict(max_depth=depth, accel=accel, no_lds=True, **{sched: True})
         r = ds.render(cam, counters=True, **kw)
         c = ds.counters()

@@ -20,7 +20,6 @@ FLAG_WAVEFRONT = 32
 FLAG_TILE_KERNEL = 64
 FLAG_DEVICE_SAMPLES = 128
 FLAG_PACKET_WALK = 256
-FLAG_STREAM_KERNELS = 512
 FEATURE_SOFT_SHADOW, FEATURE_FUZZY_REFLECTION = 1, 2
 
 
@@ -165,6 +164,7 @@ def lib():
     L.p3dh_bvh_free.argtypes = [C.c_void_p]
     L.p3dh_bvh_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.p3dh_bvh_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.p3dh_bvh_quantise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.p3d_pt_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.p3d_pt_destroy.argtypes = [C.c_void_p]
     L.p3d_pt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -352,10 +352,10 @@ class DeviceScene:
         return f.value, k.value
 
     def last_schedule(self):
-        """'wavefront', 'tree', 'tile' or 'stream': the kernel schedule of the most recent render."""
+        """'wavefront', 'tree' or 'tile': the kernel schedule of the most recent render."""
         v = C.c_int32()
         _check(lib().p3d_last_schedule(self.h, C.byref(v)), "p3d_last_schedule")
-        return ("wavefront", "tree", "tile", "stream")[v.value]
+        return ("wavefront", "tree", "tile")[v.value]
 
     def debug_set_stamps(self, ptr):
         _check(lib().p3d_debug_set_stamps(self.h, C.c_void_p(ptr or None)), "p3d_debug_set_stamps")
@@ -365,7 +365,7 @@ class DeviceScene:
         _check(lib().p3d_get_counters(self.h, C.byref(c)), "p3d_get_counters")
         return c.as_dict()
 
-    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False, stream=False):
+    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False):
         p = RenderParams()
         p.max_depth, p.accel, p.spp = int(max_depth), int(accel), int(spp)
         p.samples = samples.ctypes.data_as(C.POINTER(C.c_float)) if samples is not None else None
@@ -374,11 +374,11 @@ class DeviceScene:
         p.row_block, p.rank, p.world = int(row_block), int(rank), int(world)
         p.features = (FEATURE_SOFT_SHADOW if soft_shadow else 0) | (FEATURE_FUZZY_REFLECTION if fuzzy_reflection else 0)
         p.seed = int(seed) & 0xFFFFFFFF
-        p.flags = (FLAG_COUNTERS if counters else 0) | (FLAG_TREE_KERNEL if tree else 0) | (FLAG_NO_LDS_SCENE if no_lds else 0) | (FLAG_NO_PACKET if no_packet else 0) | (FLAG_PROFILE if profile else 0) | (FLAG_WAVEFRONT if wavefront else 0) | (FLAG_TILE_KERNEL if tile else 0) | (FLAG_DEVICE_SAMPLES if samples_ptr else 0) | (FLAG_PACKET_WALK if packet else 0) | (FLAG_STREAM_KERNELS if stream else 0)
+        p.flags = (FLAG_COUNTERS if counters else 0) | (FLAG_TREE_KERNEL if tree else 0) | (FLAG_NO_LDS_SCENE if no_lds else 0) | (FLAG_NO_PACKET if no_packet else 0) | (FLAG_PROFILE if profile else 0) | (FLAG_WAVEFRONT if wavefront else 0) | (FLAG_TILE_KERNEL if tile else 0) | (FLAG_DEVICE_SAMPLES if samples_ptr else 0) | (FLAG_PACKET_WALK if packet else 0)
         return p
 
     def render(self, cam, max_depth=4, accel=ACCEL_BVH, spp=0, samples=None, rank=0, world=1, row_block=16,
-               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, packet=False, stream=False):
+               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, packet=False):
         """Render into host numpy arrays (rows: res_y for world==1, local_rows otherwise)."""
         rows = cam.res_y if world == 1 else local_rows(cam.res_y, row_block, world)
         rgb8 = np.zeros((rows, cam.res_x, 3), np.uint8)
@@ -386,7 +386,7 @@ class DeviceScene:
         hid = np.full((rows, cam.res_x), -2, np.int32) if want_hit else None
         if samples is not None:
             samples = np.ascontiguousarray(samples, np.float32)
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, 0, packet, stream)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, 0, packet)
         o = Outputs(rgb8.ctypes.data, f32.ctypes.data if want_f32 else None,
                     hid.ctypes.data if want_hit else None, 0)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
@@ -396,10 +396,10 @@ class DeviceScene:
         return out
 
     def render_device(self, cam, rgb8_ptr=0, rgb32f_ptr=0, hit_ptr=0, max_depth=4, accel=ACCEL_BVH, spp=0,
-                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False, stream=False):
+                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False):
         """Enqueue one frame into caller-owned DEVICE buffers (raw pointers); asynchronous.  samples_ptr: the
         spp > 0 sample array as a device pointer (uploaded once by the caller) instead of `samples`."""
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, samples_ptr, packet, stream)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, samples_ptr, packet)
         o = Outputs(rgb8_ptr or None, rgb32f_ptr or None, hit_ptr or None, 1)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
 
@@ -518,9 +518,13 @@ def host_bvh(desc, leaf_max=0):
     nodes = np.zeros((info[0], 16), np.uint32)
     refs = np.zeros(info[1], np.uint32)
     lib().p3dh_bvh_dump(h, nodes.ctypes.data, refs.ctypes.data)
+    # the same nodes as scenes read from HBM get them: 32-byte pairs of 16-bit plane codes (8 dwords per node)
+    qnodes = np.zeros((info[0], 8), np.uint32)
+    qscale, qbase = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    lib().p3dh_bvh_quantise(h, qnodes.ctypes.data, qscale.ctypes.data, qbase.ctypes.data)
     lib().p3dh_bvh_free(h)
     return {"nodes": nodes, "refs": refs, "n_leaves": int(info[2]), "max_depth": int(info[3]),
-            "n_prims": int(info[4])}
+            "n_prims": int(info[4]), "qnodes": qnodes, "qscale": qscale, "qbase": qbase}
 
 
 def host_grid(desc):

@@ -83,6 +83,15 @@ void p3dh_bvh_dump(const p3dh_bvh* b, uint32_t* nodes16, uint32_t* refs) {
     memcpy(refs, b->refs.data(), b->refs.size() * sizeof(uint32_t));
 }
 
+// the 32-byte node pairs kernels that read the scene from HBM walk (csrc/scene_flatten.cpp: quantise_nodes):
+// qnodes8 = 8 dwords per node, scale3 / base3 = the de-quantisation constants (plane = base + code * scale)
+void p3dh_bvh_quantise(const p3dh_bvh* b, uint32_t* qnodes8, float* scale3, float* base3) {
+    p3d::QuantisedNodes Q;
+    p3d::quantise_nodes(b->nodes, Q);
+    memcpy(qnodes8, Q.nodes.data(), Q.nodes.size() * sizeof(p3d::QNode));
+    memcpy(scale3, Q.scale, sizeof Q.scale); memcpy(base3, Q.base, sizeof Q.base);
+}
+
 // ---- the triangle normals the device shades with (computed on the host by flatten_scene), scene order of the
 // triangles; returns their number.  For the CPU-side parity test against the reference's known answers.
 int64_t p3dh_triangle_normals(const p3d_scene_desc* d, float* out3, uint64_t cap) {

@@ -26,9 +26,6 @@ hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, int wa
 hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, int walk, int occ, unsigned waves,
                                hipStream_t stream);
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream);
-hipError_t extend_resident_waves(const LaunchParams& P, bool count, bool any, int occ, unsigned* waves);
-hipError_t launch_wf_extend(const LaunchParams& P, bool count, bool any, int occ, unsigned waves, hipStream_t stream);
-hipError_t launch_wf_shade(const LaunchParams& P, bool count, bool defer, unsigned waves, hipStream_t stream);
 hipError_t launch_clear_words(uint32_t* p, uint32_t n, hipStream_t stream);
 hipError_t wf_resident_waves(const LaunchParams& P, bool primary, bool count, bool lds, int walk, int occ, unsigned* waves);
 size_t tile_kernel_lds_bytes(const LaunchParams& P, bool lds);
@@ -137,10 +134,8 @@ struct p3d_scene {
     struct Workspace {
         RawBuf rays[kMaxDepth + 2], nodes[kMaxDepth + 2], counts;   // counts: cleared by a kernel in front of every pass
         RawBuf rng[kMaxDepth + 2];           // random-stream keys of the queued rays (stochastic features)
-        // stream schedule: hit records and occlusion words of the level being traced, its shadow queue, block cursors
-        RawBuf hits, occl, jobs, xq_ctrl;
         size_t held() const {
-            size_t b = hits.cap + occl.cap + jobs.cap;
+            size_t b = 0;
             for (auto& q : rays) b += q.cap;
             for (auto& q : nodes) b += q.cap;
             for (auto& q : rng) b += q.cap;
@@ -150,7 +145,7 @@ struct p3d_scene {
             for (auto& b : rays) b.release();
             for (auto& b : nodes) b.release();
             for (auto& b : rng) b.release();
-            counts.release(); hits.release(); occl.release(); jobs.release(); xq_ctrl.release();
+            counts.release();
         }
     } ws[kLanes];
     RawBuf wf_planes;                        // [sample][local px][3] clamped sample colours (spp > 0)
@@ -159,8 +154,6 @@ struct p3d_scene {
     RawBuf tile_ws, tile_ctrl;
     struct { uint32_t key = 0xFFFFFFFFu; size_t lds = 0; int blocks = 0; } tile_occ;   // cached occupancy query
     struct { uint32_t key = 0xFFFFFFFFu; uint32_t stack = 0; unsigned waves = 0, primary_waves = 0; } wf_occ;                 // ... of the deeper-level kernel
-    struct { uint32_t key = 0xFFFFFFFFu; uint32_t stack = 0; unsigned waves[2] = {0, 0}; } x_occ;                             // ... of the extend kernels
-    int stream_refill = 16, stream_min_blocks = 2, stream_occ = 0;   // stream schedule knobs (see LaunchParams::xq_refill)
     hipStream_t lane_stream[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     // upper limit of the workspace one frame may allocate (wavefront schedule: worst-case level queues of a band
@@ -434,9 +427,9 @@ size_t wavefront_bytes_per_pixel(int D) {
 
 constexpr int kShards = 64;   // queue shards; spreads the slot-allocation atomics. == the wave size: the deeper-level
                               // kernel holds one shard's count per lane (wf_secondary_kernel)
-// counter buffer of a workspace: [level][shard] ray counts, node counts, shadow-job counts (all cleared by the first
-// launch of a pass), then the two alternating level-1 sets and the parity words (LaunchParams::wf_alt)
-constexpr size_t kCountWords = (size_t)3 * (kMaxDepth + 2) * kShards;
+// counter buffer of a workspace: [level][shard] ray counts, node counts (all cleared by the first launch of a pass),
+// then the two alternating level-1 sets and the parity words (LaunchParams::wf_alt)
+constexpr size_t kCountWords = (size_t)2 * (kMaxDepth + 2) * kShards;
 constexpr size_t kCountBufferWords = kCountWords + 4 * kShards + 64;
 
 // One sample pass over one band of tile rows, level by level (see p3d_kernels.hip).
@@ -448,7 +441,7 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
     // scenes read from HBM wait on fetches most of the time: a register budget of 6 waves per SIMD measured 3 %
     // faster than the compiler's default there (10^6 primitives 3.19 -> 3.08 ms); LDS scenes keep the default
     const int occ = s->occupancy ? s->occupancy : (lds ? 0 : 6);
-    const size_t n_counts = (size_t)2 * (kMaxDepth + 2) * kShards;          // (the shadow-job counts belong to the stream schedule)
+    const size_t n_counts = kCountWords;
     uint32_t* counts = (uint32_t*)ws.counts.p;                              // [level][shard] ray counts, then node counts
     // No clearing launch and nothing about a frame in host state (a captured frame can be replayed any number of
     // times): the level-1 launch zeroes what the previous pass left, under a device-side parity -- see
@@ -491,68 +484,6 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
         unsigned waves = (unsigned)std::min<size_t>((total + 63) / 64, lds ? resident_waves : kPersistentWavesNarrow);
         waves = std::max<unsigned>(kShards * 4, (waves / (kShards * 4)) * (kShards * 4));   // whole workgroups per shard
         HIP_TRY(launch_wf_secondary(P, count, lds, walk, occ, waves, stream));
-    }
-    for (int l = D - 1; l >= 1; l--) {
-        P.wf_level = l;
-        P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
-        P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = l > 1 ? cap(l - 1) : 0;
-        HIP_TRY(launch_wf_resolve(P, kShards * (unsigned)s->resolve_blocks_per_shard, stream));
-    }
-    return P3D_OK;
-}
-
-// The same pass in the stream schedule: per level an extend launch (closest hits of the queued rays), a shade launch
-// that queues the hits' shadow queries, an extend launch for those, and the shade launch that finishes the nodes.
-int run_stream_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t stream, LaunchParams P, bool count, size_t shard_px,
-                    bool profile) {
-    const int D = P.max_depth;
-    const int occ = s->stream_occ;
-    uint32_t* counts = (uint32_t*)ws.counts.p;
-    P.wf_clear = counts; P.wf_clear_words = (uint32_t)kCountWords;
-    P.wf_alt = counts + kCountWords; P.wf_ctrl = counts + kCountWords + 4 * kShards;
-    auto rays = [&](int l) { return (l >= 2 && l <= D) ? (RayRec*)ws.rays[l].p : nullptr; };
-    auto nodes = [&](int l) { return (l >= 1 && l <= D - 1) ? (NodeRec*)ws.nodes[l].p : nullptr; };
-    auto qcount = [&](int l) { return counts + (size_t)l * kShards; };
-    auto ncount = [&](int l) { return counts + (size_t)(kMaxDepth + 2 + l) * kShards; };
-    auto jcount = [&](int l) { return counts + (size_t)(2 * (kMaxDepth + 2) + l) * kShards; };
-    auto cap = [&](int l) { return (uint32_t)(shard_px << (l - 1)); };
-    auto rng = [&](int l) { return (P.features && l >= 2 && l <= D) ? (uint32_t*)ws.rng[l].p : nullptr; };
-    P.wf_shards = kShards;
-    P.xq_ctrl = (uint32_t*)ws.xq_ctrl.p; P.xq_hits = (HitRec*)ws.hits.p; P.xq_occl = (uint32_t*)ws.occl.p;
-    P.xq_jobs = (ShadowJob*)ws.jobs.p;
-    P.xq_refill = s->stream_refill; P.xq_min_blocks = s->stream_min_blocks;
-    if (const char* e = getenv("P3D_STREAM_REFILL")) P.xq_refill = atoi(e);            // experiment knobs
-    if (const char* e = getenv("P3D_STREAM_MIN_BLOCKS")) P.xq_min_blocks = atoi(e);
-    double wave_scale = 1.0;
-    if (const char* e = getenv("P3D_STREAM_WAVES_PCT")) wave_scale = atoi(e) / 100.0;
-    {
-        const uint32_t okey = (count ? 1u : 0u) | ((uint32_t)occ << 5);
-        if (s->x_occ.key != okey || s->x_occ.stack != P.trav_stack_dwords) {
-            HIP_TRY(extend_resident_waves(P, count, false, occ, &s->x_occ.waves[0]));
-            HIP_TRY(extend_resident_waves(P, count, true, occ, &s->x_occ.waves[1]));
-            s->x_occ.key = okey; s->x_occ.stack = P.trav_stack_dwords;
-        }
-    }
-    for (int l = 1; l <= D; l++) {
-        P.wf_level = l;
-        P.wf_rays_in = rays(l); P.wf_count_in = l >= 2 ? qcount(l) : nullptr; P.wf_cap_in = l >= 2 ? cap(l) : 0;
-        P.wf_rays_out = rays(l + 1); P.wf_count_out = qcount(l + 1); P.wf_cap_out = cap(l + 1);
-        P.wf_rng_in = rng(l); P.wf_rng_out = rng(l + 1);
-        P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = l >= 2 ? cap(l - 1) : 0;
-        P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
-        P.xq_jcount = jcount(l); P.xq_jcap = cap(l) * std::max<uint32_t>(P.n_lights, 1u);
-        // most blocks of 64 queued rays / shadow queries the level can hold
-        const size_t blocks = l == 1 ? (size_t)P.n_tiles : ((size_t)cap(l) * kShards + 63) / 64;
-        const unsigned xw = (unsigned)std::min<size_t>(blocks, (size_t)(s->x_occ.waves[0] * wave_scale));
-        const unsigned aw = (unsigned)std::min<size_t>(blocks * std::max<uint32_t>(P.n_lights, 1u), (size_t)(s->x_occ.waves[1] * wave_scale));
-        unsigned sw = (unsigned)std::min<size_t>(blocks, (size_t)kShards * 64);
-        sw = std::max<unsigned>(kShards, (sw / kShards) * kShards);               // whole waves per shard
-        if (profile && l == 1) HIP_TRY(hipEventRecord(s->ev_prof[2], stream));
-        HIP_TRY(launch_wf_extend(P, count, false, occ, std::max(1u, xw), stream));
-        if (profile && l == 1) HIP_TRY(hipEventRecord(s->ev_prof[3], stream));
-        HIP_TRY(launch_wf_shade(P, count, false, sw, stream));
-        HIP_TRY(launch_wf_extend(P, count, true, occ, std::max(1u, aw), stream));
-        HIP_TRY(launch_wf_shade(P, count, true, sw, stream));
     }
     for (int l = D - 1; l >= 1; l--) {
         P.wf_level = l;
@@ -683,11 +614,9 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     //   WAVEFRONT  one launch per tree level over the whole frame + resolve launches
     //   TREE       one launch; each lane walks its pixel's whole tree
     // None wins everywhere, so the default is MEASURED per configuration: see SchedulePick below.
-    //   STREAM     wavefront with traversal in launches of its own: persistent waves that refill idle lanes (scenes
-    //              read from HBM, per-lane BVH walk, up to 32 lights)
-    enum { SCHED_WAVEFRONT = 0, SCHED_TREE = 1, SCHED_TILE = 2, SCHED_STREAM = 3 };
-    const uint32_t forced = prm->flags & (P3D_FLAG_TREE_KERNEL | P3D_FLAG_WAVEFRONT | P3D_FLAG_TILE_KERNEL | P3D_FLAG_STREAM_KERNELS);
-    if (forced & (forced - 1)) return fail(P3D_ERR_ARG, "at most one of P3D_FLAG_TREE_KERNEL / _WAVEFRONT / _TILE_KERNEL / _STREAM_KERNELS");
+    enum { SCHED_WAVEFRONT = 0, SCHED_TREE = 1, SCHED_TILE = 2 };
+    const uint32_t forced = prm->flags & (P3D_FLAG_TREE_KERNEL | P3D_FLAG_WAVEFRONT | P3D_FLAG_TILE_KERNEL);
+    if (forced & (forced - 1)) return fail(P3D_ERR_ARG, "at most one of P3D_FLAG_TREE_KERNEL / _WAVEFRONT / _TILE_KERNEL");
     if (stochastic && (prm->flags & P3D_FLAG_TREE_KERNEL))
         return fail(P3D_ERR_ARG, "features with random draws need the tile or the wavefront schedule");
 
@@ -740,24 +669,13 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     band_tile_rows = std::min<size_t>(band_tile_rows, (size_t)P.tiles_y);
     if (frame_streams > 1) band_tile_rows = std::min<size_t>(band_tile_rows, ((size_t)P.tiles_y + frame_streams - 1) / frame_streams);
     const bool wavefront_ok = band_tile_rows > 0;
-    // stream schedule: the wavefront queues + hit record, occlusion word and n_lights shadow jobs per ray of the widest level
-    const size_t stream_bpp = wf_bpp + ((sizeof(HitRec) + 4 + sizeof(ShadowJob) * std::max<uint32_t>(P.n_lights, 1u)) << (prm->max_depth - 1));
-    size_t stream_band_rows = std::min<size_t>(budget / lanes / (stream_bpp * tile_row_px), (size_t)P.tiles_y);
-    bool stream_ok = !lds_scene && walk == 0 && P.n_lights <= kStreamMaxLights && stream_band_rows > 0;
-    if (stream_ok) {       // a shard's widest queue must fit the 27-bit ray index of a shadow job
-        const size_t spx = ((stream_band_rows * (size_t)P.tiles_x + kShards - 1) / kShards) * 64;
-        if ((spx << (prm->max_depth - 1)) > (size_t)kJobRayMask) stream_ok = false;
-    }
 
     int sched = SCHED_TILE;
     int measuring = -1;                 // schedule this frame is timed as, for the pick below
     if (prm->flags & P3D_FLAG_TREE_KERNEL) sched = SCHED_TREE;
     else if (prm->flags & P3D_FLAG_WAVEFRONT) sched = SCHED_WAVEFRONT;
     else if (prm->flags & P3D_FLAG_TILE_KERNEL) sched = SCHED_TILE;
-    else if (prm->flags & P3D_FLAG_STREAM_KERNELS) {
-        if (!stream_ok) return fail(P3D_ERR_ARG, "P3D_FLAG_STREAM_KERNELS: needs a scene read from HBM (P3D_FLAG_NO_LDS_SCENE for small ones), accel NONE or BVH, <= 32 lights and a workspace budget that holds one band");
-        sched = SCHED_STREAM;
-    } else if (lds_scene) {
+    else if (lds_scene) {
         // scenes served from LDS: by rule (measured once, on BASELINE configs 2 and 4: a one-sample 1080p frame
         // 0.136 ms wavefront / 0.22 tile / 0.22 tree; 4096^2 x 4 samples 5.4 / 5.1 / 11.1 -- with samples the tile
         // schedule needs no per-sample planes and no summing launch).  A timing-based pick is not used here: these
@@ -769,8 +687,6 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         // random primitives: wavefront 3.7, tile 6.1, tree 9.5), so the library MEASURES: the first frames of a
         // configuration run every available schedule twice -- the first time untimed: code-object load,
         // workspace allocation -- and the fastest one stays.  All produce identical bits.
-        // (the stream schedule is opt-in only: measured slower than the best of the three on every scene tried --
-        //  dragon 4.96 ms vs 1.85, 10^5 / 10^6 random primitives 2.87 / 3.55 vs 2.34 / 3.11 -- DESIGN.md)
         constexpr int NS = 3;
         const bool avail[NS] = {wavefront_ok, !stochastic, tile_ok};
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -811,12 +727,10 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         }
     }
     // a schedule whose workspace does not fit falls back: tile -> wavefront (bands) -> tree
-    if (sched == SCHED_STREAM && !stream_ok) sched = SCHED_TILE;
     if (sched == SCHED_TILE && !tile_ok) sched = wavefront_ok ? SCHED_WAVEFRONT : SCHED_TREE;
     if (sched == SCHED_WAVEFRONT && !wavefront_ok) sched = SCHED_TREE;
     if (sched == SCHED_TREE && stochastic) return fail(P3D_ERR_LIMIT, "workspace budget too small for the schedules the features need");
-    const bool use_tree = sched == SCHED_TREE, use_tile = sched == SCHED_TILE, use_stream = sched == SCHED_STREAM;
-    if (use_stream) band_tile_rows = stream_band_rows;
+    const bool use_tree = sched == SCHED_TREE, use_tile = sched == SCHED_TILE;
     s->last_schedule = sched;
     size_t lds = use_tree ? tree_kernel_lds_bytes(P, lds_scene) : use_tile ? tile_kernel_lds_bytes(PT, lds_scene) : wavefront_lds_bytes(P, lds_scene);
     if (lds > kMaxLdsBytes) return fail(P3D_ERR_LIMIT, "BVH depth / max_depth need more LDS than a CU has");
@@ -888,16 +802,6 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
             }
             if (stochastic)
                 for (int l = 2; l <= D; l++) HIP_TRY(w.rng[l].ensure((shard_px << (l - 1)) * kShards * sizeof(uint32_t)));
-            if (use_stream) {
-                const size_t widest = (shard_px << (D - 1)) * kShards;           // rays of the widest level (>= the band's pixels)
-                HIP_TRY(w.hits.ensure(widest * sizeof(HitRec)));
-                HIP_TRY(w.occl.ensure(widest * sizeof(uint32_t)));
-                HIP_TRY(w.jobs.ensure(widest * std::max<uint32_t>(P.n_lights, 1u) * sizeof(ShadowJob)));
-                if (!w.xq_ctrl.p) {
-                    HIP_TRY(w.xq_ctrl.ensure(64 * 64 * sizeof(uint32_t)));           // one 256-byte line per shard cursor
-                    HIP_TRY(launch_clear_words((uint32_t*)w.xq_ctrl.p, 64 * 64, s->stream));
-                }
-            }
         }
         if (prm->spp > 0) {
             HIP_TRY(s->wf_planes.ensure((size_t)P.wf_nsamples * npx * 12));
@@ -921,9 +825,8 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
                 B.n_tiles = B.tiles_x * B.wf_tile_rows;
                 int chunks = (B.n_tiles + B.xcd_chunk - 1) / B.xcd_chunk;
                 B.grid_blocks = ((chunks + 7) / 8) * 8 * B.xcd_chunk;
-                int rc = use_stream ? run_stream_pass(s, s->ws[ln], lane_stream, B, count, shard_px, profile && smp == 0 && r0 == 0)
-                                    : run_wavefront_pass(s, s->ws[ln], lane_stream, B, count, lds_scene, walk, shard_px,
-                                                         profile && smp == 0 && r0 == 0);
+                int rc = run_wavefront_pass(s, s->ws[ln], lane_stream, B, count, lds_scene, walk, shard_px,
+                                            profile && smp == 0 && r0 == 0);
                 if (rc) return rc;
             }
         }
@@ -939,7 +842,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         HIP_TRY(hipEventRecord(s->ev_pick[1], s->stream));
         // a frame pushed onto another schedule by the workspace budget says the measured one is not available
         if (sched == measuring) s->pick.pending = sched;
-        else if (measuring < 3) s->pick.ms[measuring] = 3.0e38f;
+        else s->pick.ms[measuring] = 3.0e38f;
     }
     if (out->memory != 1) {
         // host planes hold res_y rows for a whole frame, p3d_local_rows() rows for a shard

@@ -70,17 +70,6 @@ struct RayRec { float o[3]; float ior; float d[3]; uint32_t link; };         // 
 struct NodeRec { float color[3]; float KR; float refl_ret[3]; uint32_t mat;
                  float refr_ret[3]; uint32_t link; };                        // 48 B
 constexpr uint32_t kLinkRefr = 0x80000000u;
-// ---- stream schedule records (traversal decoupled from shading, DESIGN.md §"Kernels")
-// What a closest-hit query returns: distance, primitive reference (kind << 30 | index; 0xFFFFFFFF = miss), scene
-// index and material of the hit -- the Hit of p3d_traverse.h as stored between the extend and the shade launches.
-struct HitRec { float t; uint32_t ref, sid, mat; };                          // 16 B
-// A queued shadow query: origin, direction and distance bound exactly as processLight() hands them to the
-// accelerator (normalised direction and len = |L| with an accelerator; the raw L and len < 0 = "no bound" without),
-// dst = light << 27 | index of the shaded ray in its shard's queue (its occlusion word gets bit `light`).
-struct ShadowJob { float o[3]; float len; float d[3]; uint32_t dst; };       // 32 B
-constexpr uint32_t kJobRayBits = 27, kJobRayMask = (1u << kJobRayBits) - 1u;
-constexpr uint32_t kStreamMaxLights = 32;
-
 struct DeviceCounters {
     unsigned long long closest_queries, shadow_queries, box_tests, sphere_tests, tri_tests,
         aabox_tests, plane_tests, pixels;
@@ -154,15 +143,6 @@ struct LaunchParams {
     // = primitive refs (kind << 30 | index, planes kind 3) in scene order; nullptr until a GRID frame is asked for
     const uint32_t* grid_cells; const uint32_t* grid_items;
     int32_t grid_n[3]; float grid_min[3], grid_max[3];
-    // ---- stream schedule: extend launches (wf_extend_kernel) trace the queued rays of a level, shade launches consume
-    // the hit records.  xq_ctrl: block cursor of shard s at word 64 * s, zeroed by the shade launch after every extend launch.  Hit / occlusion records of level 1 are indexed tile * 64 + lane, of a deeper
-    // level shard * wf_cap_in + queue index; a shard's shadow queue holds xq_jcap jobs.
-    uint32_t*  xq_ctrl;
-    HitRec*    xq_hits;
-    uint32_t*  xq_occl;
-    ShadowJob* xq_jobs; uint32_t xq_jcap; uint32_t* xq_jcount;
-    int32_t    xq_refill;             // an extend wave fetches new rays once this many of its lanes are idle
-    int32_t    xq_min_blocks;         // ... and only ceil(blocks queued / xq_min_blocks) waves of an extend launch stay
     // ---- tile schedule (wf_tile_kernel): ONE launch per frame.  Persistent 256-thread workgroups draw
     // 16x16-pixel tiles from tw_ctrl[0] and run a tile's whole ray tree level by level among themselves;
     // every queue of a tile lives in the workgroup's private slot of the workspace (slot = blockIdx.x),

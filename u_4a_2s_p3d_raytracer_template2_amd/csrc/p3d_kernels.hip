@@ -594,296 +594,6 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
 }
 
 
-// ------------------------------------------------------------------ STREAM schedule
-// Scenes read from HBM spend their time waiting on node and primitive fetches with most lanes idle: a wave that
-// traces 64 rays lasts as long as its longest walk (measured on the dragon: 30-40 % of the lanes of a VALU
-// instruction active, in every schedule above).  Here traversal is a launch of its own: PERSISTENT waves keep
-// their lanes full -- a lane whose walk ends writes its 16-byte hit record and, once xq_refill lanes are idle, the
-// wave hands them the next queued rays (blocks of 64 drawn from one cursor per shard, home shard first) while the
-// other lanes carry on where they were: per-lane state is the ray, the best hit, the node reference and the stack.
-// Shading runs in separate, fully coherent launches over the hit records (wf_shade_kernel): SPAWN queues a hit's
-// shadow queries, the same extend kernel answers them (ANY: one bit per light, atomicOr), DEFER evaluates
-// rayTracing()'s body with those answers and emits children / parks nodes exactly like the wavefront schedule.
-// Same shade_hit(), same leaf and slab code, same queues and resolve launches: bit-identical frames.
-//   per level l:  extend<closest>(l)  shade<SPAWN>(l)  extend<any>(l)  shade<DEFER>(l);  then the resolve launches.
-// MEASURED (1920x1080, depth 4): slower than the best other schedule everywhere -- dragon 4.96 ms (tree 1.85), 10^5 /
-// 10^6 random primitives 2.87 / 3.55 ms (wavefront 2.34 / 3.11) -- and insensitive to the refill threshold (8..64
-// idle lanes), to the grid (0.5x..4x the resident waves) and to drawing blocks from cursors or dealing them statically:
-// every extend launch lasts 0.2-1 ms whatever it holds, eight of them per frame.  These walks are not bound by idle
-// lanes but by the L1-miss path (tools/ubench/gather_rate.hip: a wave-load whose lanes touch 64 different lines costs
-// a CU 45-170 cycles), which keeping lanes full does not relieve.  So the schedule is opt-in (P3D_FLAG_STREAM_KERNELS),
-// never picked by the library.
-
-constexpr uint32_t kCursorStride = 64;      // words between two shards' block cursors: one 256-byte line each
-// pixel of lane `px` of band tile `tile` (a 16 x 4 tile, one wave: scenes read from HBM run one wave per workgroup)
-__device__ __forceinline__ bool stream_tile_pixel(const LaunchParams& P, int tile, int px, int& x, int& y, int& row) {
-    const int tx = tile % P.tiles_x, ty = P.wf_tile_row0 + tile / P.tiles_x;
-    x = tx * 16 + (px & 15);
-    row = ty * 4 + (px >> 4);
-    const int blk = row / P.row_block;
-    y = (blk * P.world + P.rank) * P.row_block + (row - blk * P.row_block);
-    return x < P.res_x && y < P.res_y;
-}
-
-template <bool COUNT, bool ANY, int OCC>
-__global__ __launch_bounds__(64) P3D_OCC(OCC) void wf_extend_kernel(const LaunchParams P) {
-    const GlobalScene sv = View<false>::make(P);
-    const int lane = threadIdx.x;
-    const uint32_t S = (uint32_t)P.wf_shards;                   // == 64: one shard per lane below
-    uint32_t par = 0;
-    if (!ANY && P.wf_level == 1) {
-        // first launch of a pass: the counter hand-over wf_primary_kernel does in the wavefront schedule
-        par = P.wf_ctrl[0] & 1u;
-        if (blockIdx.x == 0) {
-            if (lane == 0) P.wf_ctrl[32] = par;
-            for (uint32_t i = lane; i < P.wf_clear_words; i += 64) P.wf_clear[i] = 0u;
-            uint32_t* other = P.wf_alt + (size_t)((1u - par) * 2u) * S;
-            for (uint32_t i = lane; i < 2u * S; i += 64) other[i] = 0u;
-        }
-    } else {
-        par = P.wf_ctrl[32] & 1u;
-    }
-    // blocks of 64 jobs in shard `lane`
-    uint32_t my_jobs;
-    if (ANY) my_jobs = P.xq_jcount[lane];
-    else if (P.wf_level == 1) my_jobs = (uint32_t)lane < (uint32_t)P.n_tiles ? (((uint32_t)P.n_tiles - lane + S - 1) / S) * 64u : 0u;
-    else my_jobs = count_in_array(P, par)[lane];
-    const uint32_t my_blocks = (my_jobs + 63u) >> 6;
-    // A wave draws blocks from ONE shard's cursor (wave w: shard w % S; tiles go round the shards, so the shards
-    // hold equal work; no stealing: a scan of the 64 cursors by every leaving wave cost ~0.6 ms per launch).
-    uint32_t keep;
-    {   // short queues: only as many waves as have xq_min_blocks blocks each to keep their lanes full (at least one
-        // wave per shard); the rest leave
-        uint32_t total = my_blocks;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) total += __shfl_xor(total, d);
-        const uint32_t per = (uint32_t)(P.xq_min_blocks > 0 ? P.xq_min_blocks : 1);
-        keep = (total + per - 1) / per;
-        if (keep < S) keep = S;
-        if (keep > gridDim.x) keep = gridDim.x;
-        if (blockIdx.x >= keep) return;
-    }
-    const uint32_t home = blockIdx.x % S;
-    const uint32_t home_blocks = (uint32_t)__builtin_amdgcn_readlane((int)my_blocks, (int)home);
-    const uint32_t home_jobs = (uint32_t)__builtin_amdgcn_readlane((int)my_jobs, (int)home);
-    if (home_blocks == 0) return;
-
-    TravStack region; region.region = p3d_lds; region.lane = (uint32_t)lane; region.slots = P.trav_stack_entries;
-    P3D_HBM_STACK st(region);
-    Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
-    // per-lane walk state
-    Ray r; r.o = mk(0.0f, 0.0f, 0.0f); r.d = mk(1.0f, 0.0f, 0.0f);
-    SlabRay sl = make_slab(sv, r);
-    Hit best; best.t = 0.0f; best.ref = 0xFFFFFFFFu; best.sid = 0xFFFFFFFFu; best.mat = 0;
-    float tlimit = 0.0f; bool bounded = false;                   // ANY
-    uint32_t out = 0;                                            // where this lane's answer goes
-    int32_t cur = P3D_DONE;
-    // wave-uniform fetch state: the block in hand and how much of it is given out
-    const uint32_t pool_shard = home;
-    uint32_t pool_block = 0, pool_pos = 64;
-    bool exhausted = false;
-    const uint32_t refill = (uint32_t)(P.xq_refill > 0 ? P.xq_refill : 16);
-
-    for (;;) {
-        // ---- hand queued rays to idle lanes
-        uint64_t idle = __ballot(cur == P3D_DONE);
-        while (idle && !exhausted) {
-            if (pool_pos >= 64u) {                               // draw the next block of this wave's shard
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(&P.xq_ctrl[home * kCursorStride], 1u);
-                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                if (b >= home_blocks) { exhausted = true; break; }
-                pool_block = b; pool_pos = 0;
-            }
-            // idle lane number k of this round takes job pool_pos + k
-            const bool is_idle = cur == P3D_DONE;
-            const uint32_t k = lane_rank(idle);
-            const uint32_t px = pool_pos + k;
-            if (is_idle && px < 64u) {
-                const uint32_t i = pool_block * 64u + px;        // queue index inside the shard
-                bool valid;
-                if (ANY) {
-                    valid = i < home_jobs;
-                    if (valid) {
-                        const float4* q = reinterpret_cast<const float4*>(P.xq_jobs + (size_t)pool_shard * P.xq_jcap + i);
-                        const float4 a = q[0], b = q[1];
-                        r.o = mk(a.x, a.y, a.z); r.d = mk(b.x, b.y, b.z);
-                        bounded = a.w >= 0.0f; tlimit = a.w;
-                        const uint32_t dst = __float_as_uint(b.w);
-                        out = dst;                               // light << 27 | ray index (resolved when the answer is written)
-                        best.sid = pool_shard;
-                    }
-                } else if (P.wf_level == 1) {
-                    const int tile = (int)(pool_shard + S * pool_block);
-                    int x, y, row;
-                    valid = stream_tile_pixel(P, tile, (int)px, x, y, row);
-                    if (valid) r = camera_ray(P, x, y, P.wf_sample);
-                    out = (uint32_t)tile * 64u + px;
-                } else {
-                    valid = i < home_jobs;
-                    if (valid) {
-                        const float4* q = reinterpret_cast<const float4*>(P.wf_rays_in + (size_t)pool_shard * P.wf_cap_in + i);
-                        const float4 a = q[0], b = q[1];
-                        r.o = mk(a.x, a.y, a.z); r.d = mk(b.x, b.y, b.z);
-                    }
-                    out = pool_shard * P.wf_cap_in + i;
-                }
-                if (valid) {
-                    // what closest_hit() / any_hit() do before their walk (p3d_traverse.h)
-                    cur = 0; st.sp = 0;
-                    if (ANY) {
-                        if (COUNT) ctr.shadow++;
-                        bool occ = false;
-                        if (P.n_planes) {
-                            const bool gate = !bounded || ref_unit_box_hit(r);
-                            if (gate)
-                                for (uint32_t pi = 0; pi < P.n_planes && !occ; pi++) {
-                                    const PlaneRec pl = P.planes[pi];
-                                    float t;
-                                    if (COUNT) ctr.pln++;
-                                    if (hit_plane(r, mk(pl.nx, pl.ny, pl.nz), pl.d, t) && (!bounded || t < tlimit)) occ = true;
-                                }
-                        }
-                        if (!bounded) tlimit = 3.402823466e+38f;
-                        if (occ) {
-                            atomicOr(&P.xq_occl[(P.wf_level == 1 ? 0u : best.sid * P.wf_cap_in) + (out & kJobRayMask)], 1u << (out >> kJobRayBits));
-                            cur = P3D_DONE;
-                        }
-                    } else {
-                        if (COUNT) ctr.closest++;
-                        best.t = 3.402823466e+38f; best.ref = 0xFFFFFFFFu; best.sid = 0xFFFFFFFFu; best.mat = 0;
-                        for (uint32_t pi = 0; pi < P.n_planes; pi++) {
-                            const PlaneRec pl = P.planes[pi];
-                            float t;
-                            if (COUNT) ctr.pln++;
-                            if (hit_plane(r, mk(pl.nx, pl.ny, pl.nz), pl.d, t)) {
-                                const PrimMeta m = P.plane_meta[pi];
-                                if (t < best.t || (t == best.t && m.scene_id < best.sid)) {
-                                    best.t = t; best.ref = (3u << kRefKindShift) | pi; best.sid = m.scene_id; best.mat = m.material;
-                                }
-                            }
-                        }
-                    }
-                    sl = make_slab(sv, r);
-                }
-            }
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            pool_pos += n_idle;                                  // (a block's tail past 64 is simply not there)
-            idle = __ballot(cur == P3D_DONE);
-            if (pool_pos < 64u) break;                           // every idle lane was offered a job
-        }
-        uint64_t busy = __ballot(cur != P3D_DONE);
-        if (!busy) { if (exhausted) break; else continue; }
-        // ---- walk: closest_hit() / any_hit() of p3d_traverse.h, a lane at a time, until enough lanes are idle again
-        for (;;) {
-            const bool walking = cur != P3D_DONE;
-            while (cur >= 0) {
-                float tn0, tn1; bool h0, h1; int32_t c0, c1;
-                const float lim = ANY ? tlimit : best.t;
-                node_test(sv, sl, cur, lim, h0, h1, tn0, tn1, c0, c1);
-                if (COUNT) ctr.box += 2;
-                if (h0 && h1) {
-                    const bool swap = tn1 < tn0;
-                    st.push(swap ? c0 : c1, swap ? tn0 : tn1);
-                    cur = swap ? c1 : c0;
-                } else if (h0) cur = c0;
-                else if (h1) cur = c1;
-                else if (!st.pop(lim, cur)) cur = P3D_DONE;
-            }
-            if (cur != P3D_DONE) {                               // a leaf
-                if (ANY) {
-                    if (leaf_any<COUNT>(P, sv, r, cur, bounded, tlimit, ctr)) {
-                        atomicOr(&P.xq_occl[(P.wf_level == 1 ? 0u : best.sid * P.wf_cap_in) + (out & kJobRayMask)], 1u << (out >> kJobRayBits));
-                        cur = P3D_DONE;
-                    } else if (!st.pop(cur)) cur = P3D_DONE;
-                } else {
-                    leaf_closest<COUNT>(P, sv, r, cur, best, ctr);
-                    if (!st.pop(best.t, cur)) cur = P3D_DONE;
-                }
-            }
-            if (!ANY && walking && cur == P3D_DONE) {            // this lane's walk just ended: its answer
-                float4* hq = reinterpret_cast<float4*>(P.xq_hits + out);
-                *hq = make_float4(best.t, __uint_as_float(best.ref), __uint_as_float(best.sid), __uint_as_float(best.mat));
-            }
-            busy = __ballot(cur != P3D_DONE);
-            if (!busy) break;
-            if (!exhausted && 64u - (uint32_t)__popcll(busy) >= refill) break;
-        }
-    }
-    flush_counters<COUNT>(P, ctr, 0u);
-    // (the cursors are zeroed again by the shade launch that follows every extend launch)
-}
-
-// Shading launches of the stream schedule.  MODE = WALK_SPAWN (queue the shadow queries of every hit) or WALK_DEFER
-// (rayTracing()'s body with their answers; children and parked nodes as in the wavefront schedule).  Level 1: one
-// wave per 16x4 tile (hardware-dispatched, XCD chunk map); deeper levels: the waves of a shard stride over its queue.
-template <bool COUNT, int MODE, bool STOCH>
-__global__ __launch_bounds__(64) void wf_shade_kernel(const LaunchParams P) {
-    const GlobalScene sv = View<false>::make(P);
-    const uint32_t S = (uint32_t)P.wf_shards;
-    const int lane = threadIdx.x;
-    const uint32_t par = P.wf_ctrl[32] & 1u;
-    if (blockIdx.x == 0) {
-        if (MODE == WALK_SPAWN && P.wf_level == 1 && lane == 0) P.wf_ctrl[0] = 1u - par;   // the next pass takes the other set
-        P.xq_ctrl[lane * kCursorStride] = 0u;                   // block cursors of the extend launch that just ended
-    }
-    Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
-    TravCtx tc;
-    tc.lane.region = nullptr; tc.lane.lane = 0; tc.lane.slots = 0; tc.wave.base = nullptr;
-    if (P.wf_level == 1) {
-        int x, y, row, tile;
-        const bool valid = tile_pixel(P, x, y, row, &tile);
-        if (__ballot(valid) == 0) return;
-        const uint32_t s = (uint32_t)tile % S;
-        const Shard sh = shard_of(P, s, par);
-        const size_t p = (size_t)row * P.res_x + x;
-        const uint32_t idx = (uint32_t)tile * 64u + (uint32_t)lane;
-        Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
-        Hit h; h.t = 3.402823466e+38f; h.ref = 0xFFFFFFFFu; h.sid = 0xFFFFFFFFu; h.mat = 0;
-        tc.dq.occl = 0; tc.dq.jobs = P.xq_jobs + (size_t)s * P.xq_jcap; tc.dq.jcount = P.xq_jcount + s; tc.dq.ray = idx;
-        if (valid) {
-            ray = camera_ray(P, x, y, P.wf_sample);
-            const float4 hq = *reinterpret_cast<const float4*>(P.xq_hits + idx);
-            h.t = hq.x; h.ref = __float_as_uint(hq.y); h.sid = __float_as_uint(hq.z); h.mat = __float_as_uint(hq.w);
-            if (MODE == WALK_SPAWN) P.xq_occl[idx] = 0u; else tc.dq.occl = P.xq_occl[idx];
-        }
-        const uint32_t rng = STOCH ? rng_mix(rng_mix(P.seed, (uint32_t)(y * P.res_x + x)), (uint32_t)P.wf_sample) : 0u;
-        const NodeOut o = shade_hit<COUNT, MODE, GlobalScene, STOCH>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr, rng);
-        if (MODE == WALK_DEFER) {
-            if (valid && P.hit_id && P.wf_sample == 0) P.hit_id[p] = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid;
-            emit(P, sh, 1, valid, (uint32_t)p, 1.0f, o);
-            if (valid) flush_counters<COUNT>(P, ctr, P.wf_sample == 0 ? 1u : 0u);
-        }
-        return;
-    }
-    const uint32_t wave_id = blockIdx.x, n_waves = gridDim.x;
-    const uint32_t per_shard = n_waves / S, s = wave_id % S;
-    const Shard sh = shard_of(P, s, par);
-    tc.dq.jobs = P.xq_jobs + (size_t)s * P.xq_jcap; tc.dq.jcount = P.xq_jcount + s;
-    for (uint32_t base = (wave_id / S) * 64u; base < sh.count_in; base += per_shard * 64u) {
-        const uint32_t i = base + lane;
-        const bool valid = i < sh.count_in;
-        const uint32_t idx = s * P.wf_cap_in + i;
-        uint32_t link = 0, rng = 0; float ior_1 = 1.0f;
-        Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
-        Hit h; h.t = 3.402823466e+38f; h.ref = 0xFFFFFFFFu; h.sid = 0xFFFFFFFFu; h.mat = 0;
-        tc.dq.occl = 0; tc.dq.ray = i;
-        if (valid) {
-            const float4* rq = reinterpret_cast<const float4*>(sh.rays_in + i);
-            const float4 a = rq[0], b = rq[1];
-            ray.o = mk(a.x, a.y, a.z); ray.d = mk(b.x, b.y, b.z);
-            ior_1 = a.w; link = __float_as_uint(b.w);
-            if (STOCH) rng = sh.rng_in[i];
-            const float4 hq = *reinterpret_cast<const float4*>(P.xq_hits + idx);
-            h.t = hq.x; h.ref = __float_as_uint(hq.y); h.sid = __float_as_uint(hq.z); h.mat = __float_as_uint(hq.w);
-            if (MODE == WALK_SPAWN) P.xq_occl[idx] = 0u; else tc.dq.occl = P.xq_occl[idx];
-        }
-        const NodeOut o = shade_hit<COUNT, MODE, GlobalScene, STOCH>(P, sv, ray, h, valid, P.wf_level, ior_1, tc, ctr, rng);
-        if (MODE == WALK_DEFER) emit(P, sh, P.wf_level, valid, link, ior_1, o);
-    }
-    if (MODE == WALK_DEFER) flush_counters<COUNT>(P, ctr, 0u);
-}
-
 // ------------------------------------------------------------------ TREE schedule
 // shade-stack frame: 12 dwords.  STRIDE 64: in LDS, [field][lane] (scenes rendered from an LDS copy, and trees deeper
 // than 8 levels).  STRIDE 1: in the lane's PRIVATE memory (scratch) -- scenes read from HBM are bound by how many waves
@@ -1197,39 +907,6 @@ hipError_t launch_wf_tile(const LaunchParams& P, bool count, bool lds, int walk,
                              tile_kernel_lds_bytes(P, lds), stream);
 }
 
-
-// ---- stream schedule
-static const void* extend_fn(bool count, bool any, int occ) {
-    if (count) return any ? fn_ptr(wf_extend_kernel<true, true, 1>) : fn_ptr(wf_extend_kernel<true, false, 1>);
-    if (occ == 6) return any ? fn_ptr(wf_extend_kernel<false, true, 6>) : fn_ptr(wf_extend_kernel<false, false, 6>);
-    if (occ == 8) return any ? fn_ptr(wf_extend_kernel<false, true, 8>) : fn_ptr(wf_extend_kernel<false, false, 8>);
-    return any ? fn_ptr(wf_extend_kernel<false, true, 1>) : fn_ptr(wf_extend_kernel<false, false, 1>);
-}
-static const void* shade_fn(bool count, bool defer, bool stoch) {
-    if (stoch) {
-        if (count) return defer ? fn_ptr(wf_shade_kernel<true, WALK_DEFER, true>) : fn_ptr(wf_shade_kernel<true, WALK_SPAWN, true>);
-        return defer ? fn_ptr(wf_shade_kernel<false, WALK_DEFER, true>) : fn_ptr(wf_shade_kernel<false, WALK_SPAWN, true>);
-    }
-    if (count) return defer ? fn_ptr(wf_shade_kernel<true, WALK_DEFER, false>) : fn_ptr(wf_shade_kernel<true, WALK_SPAWN, false>);
-    return defer ? fn_ptr(wf_shade_kernel<false, WALK_DEFER, false>) : fn_ptr(wf_shade_kernel<false, WALK_SPAWN, false>);
-}
-// persistent grid of the extend kernel: one wave per workgroup, as many as fit the device
-hipError_t extend_resident_waves(const LaunchParams& P, bool count, bool any, int occ, unsigned* waves) {
-    int per_cu = 0, dev = 0, cus = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, extend_fn(count, any, occ), 64, (size_t)P.trav_stack_dwords * 4);
-    if (e != hipSuccess) return e;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-    *waves = (unsigned)((per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1));
-    return hipSuccess;
-}
-hipError_t launch_wf_extend(const LaunchParams& P, bool count, bool any, int occ, unsigned waves, hipStream_t stream) {
-    return launch_by_pointer(extend_fn(count, any, occ), P, dim3(waves), dim3(64), (size_t)P.trav_stack_dwords * 4, stream);
-}
-// level 1: one wave per tile (P.grid_blocks); deeper levels: `waves` striding over the shards' queues
-hipError_t launch_wf_shade(const LaunchParams& P, bool count, bool defer, unsigned waves, hipStream_t stream) {
-    return launch_by_pointer(shade_fn(count, defer, P.features != 0), P, dim3(P.wf_level == 1 ? (unsigned)P.grid_blocks : waves), dim3(64), 0, stream);
-}
 
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream) {
     hipLaunchKernelGGL(wf_resolve_kernel, dim3(blocks), dim3(256), 0, stream, P);

@@ -47,11 +47,8 @@ __device__ __forceinline__ Mtl load_material(const SV& sv, uint32_t m) {
 // Traversal context of a lane: its private stack (per-lane walk) and its wave's shared stack
 // (packet walk).  WALK selects the walk at compile time: 0 = per-lane BVH walk, 1 = wave-wide (packet) BVH
 // walk -- identical results -- and 2 = the reference's uniform grid (GRID mode, accel 1: its own semantics).
-// Stream schedule (shade launches; no traversal in the kernel): WALK_SPAWN queues the shadow queries of a hit
-// instead of tracing them and stops after the light loop, WALK_DEFER reads their answers (one bit per light).
-struct Deferred { uint32_t occl; ShadowJob* jobs; uint32_t* jcount; uint32_t ray; };
-struct TravCtx { TravStack lane; WaveStack wave; Deferred dq; };
-enum { WALK_LANE = 0, WALK_PACKET = 1, WALK_GRID = 2, WALK_SPAWN = 3, WALK_DEFER = 4 };
+struct TravCtx { TravStack lane; WaveStack wave; };
+enum { WALK_LANE = 0, WALK_PACKET = 1, WALK_GRID = 2 };
 
 template <bool COUNT, int WALK, class SV>
 __device__ __forceinline__ Hit find_closest(const LaunchParams& P, const SV& sv, const Ray& ray, bool active,
@@ -67,28 +64,11 @@ __device__ __forceinline__ Hit find_closest(const LaunchParams& P, const SV& sv,
 // direction and t < |L| (BVH::Traverse(Ray&), RT/bvh.cpp:351-352).
 template <bool COUNT, int WALK, class SV>
 __device__ __forceinline__ bool light_occluded(const LaunchParams& P, const SV& sv, V3 L, V3 precise, bool need,
-                                               const TravCtx& tc, Ctr& ctr, uint32_t light = 0u) {
-    if (WALK == WALK_DEFER) return need && ((tc.dq.occl >> light) & 1u) != 0u;
+                                               const TravCtx& tc, Ctr& ctr) {
     Ray sr; sr.o = precise; sr.d = L;
     float length = 0.0f;
     const bool bounded = WALK == WALK_GRID || P.accel != 0;
     if (bounded && need) { length = vlen(sr.d); sr.d = normalized(sr.d); }
-    if (WALK == WALK_SPAWN) {
-        // all lanes of the wave arrive together: slots by ballot + prefix count, one atomic per wave
-        const uint64_t m = __ballot(need);
-        if (m == 0) return false;
-        const int first = (int)__builtin_ctzll(m);
-        uint32_t base = 0;
-        if ((int)(threadIdx.x & 63) == first) base = atomicAdd(tc.dq.jcount, (uint32_t)__popcll(m));
-        base = __shfl(base, first);
-        if (need) {
-            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            float4* q = reinterpret_cast<float4*>(tc.dq.jobs + slot);
-            q[0] = make_float4(sr.o.x, sr.o.y, sr.o.z, bounded ? length : -1.0f);
-            q[1] = make_float4(sr.d.x, sr.d.y, sr.d.z, __uint_as_float((light << kJobRayBits) | tc.dq.ray));
-        }
-        return true;
-    }
     if (WALK == WALK_PACKET) return any_hit_packet<COUNT>(P, sv, sr, need, bounded, length, tc.wave, ctr);
     if (WALK == WALK_GRID) return need ? grid_any<COUNT>(P, sv, sr, length, ctr) : false;   // Grid::Traverse(Ray&), RT/grid.cpp:313
     return need ? any_hit<COUNT>(P, sv, sr, bounded, length, tc.lane, ctr) : false;
@@ -209,9 +189,9 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
 #else
             const bool need = hit && dot(L, normal) > 0.0f;              // RT/main.cpp:476
 #endif
-            if (light_occluded<COUNT, WALK>(P, sv, L, precise, need, tc, ctr, l0 + i)) occluded |= (1ull << i);
+            if (light_occluded<COUNT, WALK>(P, sv, L, precise, need, tc, ctr)) occluded |= (1ull << i);
         }
-        if (WALK != WALK_SPAWN && hit) {
+        if (hit) {
             Mtl Ml = load_material(sv, h.mat);
             for (uint32_t i = 0; i < ln; i++) {
                 if (occluded & (1ull << i)) continue;
@@ -222,7 +202,6 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
             }
         }
     }
-    if (WALK == WALK_SPAWN) return o;               // the shadow queries are queued: this launch is done with the hit
     if (!hit) {
         o.ret = mk(P.bg[0], P.bg[1], P.bg[2]);
         return o;
