@@ -197,7 +197,10 @@ def roofline_from_profiles(workload, live):
     def total_ns(r):
         return float(r.get("TotalDurationNs") or r.get("TotalDuration(ns)") or 0.0)
     ray = [r for r in stats if "<true" not in r["Name"]] or stats        # not the counting builds (first template argument)
-    top = max(ray, key=total_ns)
+    # ... of the schedule this run used (a profile run may hold frames of other schedules too: measured picks, comparisons)
+    mine = {"tree": ("whitted_tree_kernel",), "tile": ("wf_tile_kernel",),
+            "wavefront": ("wf_primary_kernel", "wf_secondary_kernel", "wf_resolve_kernel")}.get(live.get("schedule"), ())
+    top = max([r for r in ray if any(m in r["Name"] for m in mine)] or ray, key=total_ns)
     kernels = {}
     for r in ray:
         name = r["Name"]
@@ -350,8 +353,26 @@ def main():
         ident = [P.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         assert isinstance(ident[0], bytes) and len(ident[0]) == 128
+        comm_error = None
         if not rehearsal:
-            comm = P.Comm.create(ident[0], rank, world, local_rank)
+            try:
+                comm = P.Comm.create(ident[0], rank, world, local_rank)
+            except Exception as e:                          # reported in the JSON line; the run goes on through host memory
+                comm_error = "%s: %s" % (type(e).__name__, e)
+        failed = torch.tensor([1 if comm_error else 0])
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed.item()):
+            # safety net, not a product path: some rank could not build the RCCL communicator.  Every rank then moves
+            # its tile buffers through host memory with gloo (like the rehearsal mode) and the line says so.
+            if comm is not None:
+                comm.close()
+                comm = None
+            errs = [None] * world
+            dist.all_gather_object(errs, comm_error)
+            comm_error = next((e for e in errs if e), "unknown")
+            if args.workload == "pathtracer":
+                raise SystemExit("p3d_comm_create failed: " + comm_error)
+    host_gather = world > 1 and comm is None
 
     if args.workload == "pathtracer":
         if rehearsal:
@@ -479,7 +500,7 @@ def main():
             render_frames(main_stream, buf)
         if world > 1:
             comm_stream.wait_stream(main_stream)
-            if rehearsal:
+            if host_gather:
                 torch.cuda.synchronize()
                 src = tile_sets[buf].cpu()
                 dst = list(torch.zeros((world,) + tuple(src.shape), dtype=torch.uint8).unbind(0)) if rank == 0 else None
@@ -533,7 +554,7 @@ def main():
         final = (frames[B - 1] if world > 1 else tile_sets[(state["next"] - 1) % nbuf][B - 1][:H]).cpu().numpy()
         total_rays = rays_frame * B * args.steps
         dominant = {"tree": "p3d::whitted_tree_kernel", "tile": "p3d::wf_tile_kernel", "wavefront": "p3d::wf_primary_kernel"}[chosen]
-        live = {"kernel": dominant, "kernel_ms": kern_ms, "frame_ms": frame_dev_ms, "alg_bytes": int(alg_bytes),
+        live = {"kernel": dominant, "schedule": chosen, "kernel_ms": kern_ms, "frame_ms": frame_dev_ms, "alg_bytes": int(alg_bytes),
                 "alg_gbps": alg_bytes / (frame_dev_ms * 1e-3) / 1e9}
         line = {
             "metric": "Mrays/s + ms/frame @%dx%d depth%d" % (W, H, depth),
@@ -554,8 +575,11 @@ def main():
             "config": {"workload": ("SURVEY 8d scaling scene, %d primitives, 1920x1080 depth 4 BVH" % args.prims) if synthetic else wl["name"],
                        "frames_per_step": B, "frames_in_flight": F, "hip_graph": graphs is not None,
                        "schedule": chosen + (" (forced)" if sched else " (library default)"),
-                       "gather": None if world == 1 else ("p3d_gather over RCCL on a communication stream, %s"
-                                                          % ("two buffer sets (overlaps the next step)" if nbuf == 2 else "one buffer set")),
+                       "gather": None if world == 1 else
+                                 ("FALLBACK gloo through host memory: " + ("rehearsal mode" if rehearsal else "p3d_comm_create failed (%s)" % comm_error))
+                                 if host_gather else
+                                 ("p3d_gather over RCCL on a communication stream, %s"
+                                  % ("two buffer sets (overlaps the next step)" if nbuf == 2 else "one buffer set")),
                        "rays_per_frame": int(rays_frame),
                        "row_block": ROW_BLOCK,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved 16-row blocks + one RCCL gather to rank 0 through the C-ABI" % world,
