@@ -310,7 +310,7 @@ def main():
                     help="independent frames overlapped on separate HIP streams (each with its own scene handle and "
                          "workspace); 1 = strictly one frame after the other; default min(frames per step, 3 x N)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the frames of a step as ONE captured HIP graph (auto: when the frame is tiled over several GPUs)")
+                    help="replay the frames of a step as ONE captured HIP graph (auto = off: measured slower than eager launches)")
     ap.add_argument("--gather", choices=["pipelined", "sync"], default="pipelined",
                     help="N > 1: two tile-buffer sets, so that a step's gather overlaps the next step's rendering, or one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -408,10 +408,13 @@ def main():
     # The deeper tree levels of one 1080p frame are too few rays to fill 256 CUs, so consecutive frames --
     # independent work -- are overlapped on F streams, one scene handle each.  With the frame tiled over N GPUs
     # each rank holds 1/N of every frame, so it takes N times as many frames in flight to fill it.
-    F = args.frames_in_flight if args.frames_in_flight > 0 else 3 * world
+    # Measured (tools/shard_probe.py, explicit non-blocking streams): whole frame 4 in flight 0.072 ms/frame (3: 0.075,
+    # 6: 0.077, 12: 0.074); half a frame 4: 0.038-0.042; a quarter / an eighth: 4, 8 and 12 within 3 % of each other.
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (4 if world <= 2 else 12)
     F = max(1, min(F, B))
     main_stream = torch.cuda.current_stream()
-    streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
+    # every frame stream is an explicit non-blocking stream; the (default) main stream only forks / joins them
+    streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
     handles = []
     for st in streams:
         h = make_handle()
@@ -447,14 +450,18 @@ def main():
     my_rays = ctr["rays"]
     alg_bytes = ctr["algorithmic_bytes"] + 3 * ctr["pixels"]          # + rgb8 written per pixel
 
-    def render_frames(lead, buf):
-        """The B frames of a step into tile set `buf`: fork the side streams off `lead`, enqueue, join back."""
-        for k in range(1, F):
-            streams[k].wait_stream(lead)
+    def render_frames(lead, buf, join=True):
+        """The B frames of a step into tile set `buf`: fork the side streams off `lead`, enqueue, join back.
+        join=False (one GPU, nothing downstream of a step on the device): the F streams simply run on -- the frames of
+        consecutive steps are independent, and the barrier around the timed region waits for every stream."""
+        if join:
+            for k in range(F):
+                streams[k].wait_stream(lead)
         for f in range(B):
             handles[f % F].render_device(cam, rgb8_ptr=tile_sets[buf][f].data_ptr(), **sched, **kw)
-        for k in range(1, F):
-            lead.wait_stream(streams[k])
+        if join:
+            for k in range(F):
+                lead.wait_stream(streams[k])
 
     # let every handle settle its schedule ALONE: for scenes read from HBM the library times every schedule on the
     # first frames of a configuration, and frames running next to them on other streams would falsify the timing
@@ -464,23 +471,22 @@ def main():
         h.sync()
     torch.cuda.synchronize()
     graphs = None
-    want_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
+    # eager launches by default: replaying a step as one captured graph measured SLOWER on a rank's share of a tiled
+    # frame (tools/shard_probe.py, 1/8 of config 2: 0.025-0.029 ms/frame eager, 0.033-0.035 as a graph; whole frame:
+    # 0.073-0.076 vs 0.076-0.079)
+    want_graph = args.graph == "on"
     if want_graph:
         try:
             captured = []
             for buf in range(nbuf):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    lead = torch.cuda.current_stream()
-                    handles[0].set_stream(lead.cuda_stream)
-                    render_frames(lead, buf)
-                handles[0].set_stream(main_stream.cuda_stream)
+                    render_frames(torch.cuda.current_stream(), buf)
                 g.replay()
                 torch.cuda.synchronize()
                 captured.append(g)
             graphs = captured
         except Exception as exc:                     # capture not possible here: keep launching eagerly
-            handles[0].set_stream(main_stream.cuda_stream)
             if args.graph == "on":
                 raise
             if rank == 0:
@@ -497,7 +503,7 @@ def main():
         if graphs is not None:
             graphs[buf].replay()
         else:
-            render_frames(main_stream, buf)
+            render_frames(main_stream, buf, join=world > 1)
         if world > 1:
             comm_stream.wait_stream(main_stream)
             if host_gather:
