@@ -26,6 +26,7 @@ hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, int wa
 hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, int walk, int occ, unsigned waves,
                                hipStream_t stream);
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream);
+hipError_t launch_wf_resolve_fused(const LaunchParams& P, const ResolveLevels& R, unsigned shards, hipStream_t stream);
 hipError_t launch_clear_words(uint32_t* p, uint32_t n, hipStream_t stream);
 hipError_t wf_resident_waves(const LaunchParams& P, bool primary, bool count, bool lds, int walk, int occ, unsigned* waves);
 size_t tile_kernel_lds_bytes(const LaunchParams& P, bool lds);
@@ -183,6 +184,7 @@ struct p3d_scene {
     int xcd_chunk = 1;
     int frame_streams = 1;               // bands of a one-sample frame run concurrently on this many streams (experiment knob)
     int resolve_blocks_per_shard = 16;   // a resolve launch is latency-bound: few nodes per thread, many threads
+    int fused_resolve_shard_px = 8192;   // frames with at most this many pixels per shard resolve all levels in one launch
     unsigned long long* dbg_stamps = nullptr;
     int occupancy = 0;     // 0 = compiler default register budget, else 5 / 6 / 8 waves per SIMD
 };
@@ -291,6 +293,7 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     s->device = device;
     if (const char* e = getenv("P3D_FRAME_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= kLanes) s->frame_streams = v; }
     if (const char* e = getenv("P3D_RESOLVE_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 64) s->resolve_blocks_per_shard = v; }   // tuning experiments
+    if (const char* e = getenv("P3D_FUSED_RESOLVE_PX")) s->fused_resolve_shard_px = atoi(e);
     auto bail = [&](hipError_t e, const char* what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(e);
         p3d_scene_destroy(s);
@@ -484,6 +487,16 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
         unsigned waves = (unsigned)std::min<size_t>((total + 63) / 64, lds ? resident_waves : kPersistentWavesNarrow);
         waves = std::max<unsigned>(kShards * 4, (waves / (kShards * 4)) * (kShards * 4));   // whole workgroups per shard
         HIP_TRY(launch_wf_secondary(P, count, lds, walk, occ, waves, stream));
+    }
+    if (D >= 3 && shard_px <= (size_t)s->fused_resolve_shard_px) {
+        // small frame (a rank's share of a tiled frame): all resolve levels in ONE launch, a workgroup per shard
+        ResolveLevels R;
+        memset(&R, 0, sizeof R);
+        for (int l = 1; l <= D - 1; l++) { R.nodes[l] = nodes(l); R.ncount[l] = ncount(l); R.cap[l] = cap(l); }
+        R.top = D - 1;
+        P.wf_level = 1;
+        HIP_TRY(launch_wf_resolve_fused(P, R, kShards, stream));
+        return P3D_OK;
     }
     for (int l = D - 1; l >= 1; l--) {
         P.wf_level = l;

@@ -152,6 +152,10 @@ struct LaunchParams {
     uint32_t  tw_rays_off, tw_nodes_off, tw_rng_off;     // byte offsets of the three regions inside a slot
 };
 
+// Every level of a pass for the fused resolve launch (small frames / shards, wf_resolve_fused_kernel): level l's
+// parked nodes (shard s at nodes[l] + s * cap[l]) and their per-shard counts; levels top .. 1 are combined.
+struct ResolveLevels { NodeRec* nodes[18]; const uint32_t* ncount[18]; uint32_t cap[18]; int32_t top; };
+
 // tile schedule geometry: a tile is 16 x 16 pixels = one 256-thread workgroup = 4 waves of 16 x 4
 constexpr uint32_t kTilePx = 256;
 constexpr int kMaxTileLevels = 18;        // max_depth <= 16: levels 0..17 index the per-tile counters

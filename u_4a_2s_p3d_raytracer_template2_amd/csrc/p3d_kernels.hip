@@ -411,6 +411,31 @@ __global__ __launch_bounds__(256) void wf_resolve_kernel(const LaunchParams P) {
     }
 }
 
+// The same for ALL levels in one launch, one 1024-thread workgroup per shard: a ray never leaves its pixel's shard, so a
+// shard's levels only depend on each other and a __syncthreads() between levels replaces the launch boundary.  For
+// small frames -- a rank's share of a frame tiled over several GPUs -- where a level holds a few nodes per thread and a
+// frame is bound by the number of launches (tools/shard_probe.py); large frames keep one wide launch per level.
+__global__ __launch_bounds__(1024) void wf_resolve_fused_kernel(const LaunchParams P, const ResolveLevels R) {
+    const uint32_t s = blockIdx.x, par = P.wf_ctrl[32] & 1u;
+    const GlobalScene gv = View<false>::make(P);
+    for (int l = R.top; l >= 1; l--) {
+        Shard sh;
+        sh.rays_in = nullptr; sh.count_in = 0; sh.rays_out = nullptr; sh.count_out = nullptr; sh.rng_in = nullptr; sh.rng_out = nullptr;
+        sh.nodes_self = R.nodes[l] + (size_t)s * R.cap[l];
+        sh.nodes_parent = l > 1 ? R.nodes[l - 1] + (size_t)s * R.cap[l - 1] : nullptr;
+        sh.ncount_self = nullptr;
+        const uint32_t count = l == 1 ? (P.wf_alt + (size_t)(par * 2u + 1u) * (uint32_t)P.wf_shards)[s] : R.ncount[l][s];
+        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+            const float4* nd = reinterpret_cast<const float4*>(sh.nodes_self + i);
+            float4 a = nd[0], b = nd[1], c = nd[2];
+            Mtl M = load_material(gv, __float_as_uint(b.w));
+            V3 ret = combine_node(mk(a.x, a.y, a.z), a.w, M.spec, mk(b.x, b.y, b.z), mk(c.x, c.y, c.z));
+            deliver(P, sh, l, __float_as_uint(c.w), ret);
+        }
+        __syncthreads();             // the workgroup's own stores are visible to it after the barrier
+    }
+}
+
 // ------------------------------------------------------------------ TILE schedule
 // ONE launch per frame.  The wavefront schedule above spends six of its seven launches on the deeper
 // levels of a 1080p frame, each lasting as long as one or two incoherent ray steps of a wave whatever
@@ -908,6 +933,10 @@ hipError_t launch_wf_tile(const LaunchParams& P, bool count, bool lds, int walk,
 }
 
 
+hipError_t launch_wf_resolve_fused(const LaunchParams& P, const ResolveLevels& R, unsigned shards, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_resolve_fused_kernel, dim3(shards), dim3(1024), 0, stream, P, R);
+    return hipGetLastError();
+}
 hipError_t launch_wf_resolve(const LaunchParams& P, unsigned blocks, hipStream_t stream) {
     hipLaunchKernelGGL(wf_resolve_kernel, dim3(blocks), dim3(256), 0, stream, P);
     return hipGetLastError();
