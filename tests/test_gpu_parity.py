@@ -137,6 +137,20 @@ def test_schedules_and_scene_placements_are_bit_identical():
                 assert a["counters"][k] == b["counters"][k], (name, kw, k)
 
 
+@pytest.mark.parametrize("depth", [3, 7, 10])
+def test_tree_schedule_frame_placements(depth):
+    """The tree kernel keeps its per-level frames in private memory for scenes read from HBM up to depth 8 (36 or 84
+    dwords per lane) and in LDS otherwise: depths on both sides of each limit, against the wavefront schedule."""
+    m = dict(CASES["c2_mount_low_256x144_d4_bvh"])
+    m["max_depth"] = depth
+    a = gpu_render(m, counters=True, wavefront=True)
+    for kw in (dict(tree=True), dict(tree=True, no_lds=True), dict(tile=True, no_lds=True)):
+        b = gpu_render(m, counters=True, **kw)
+        assert np.array_equal(a["rgb8"], b["rgb8"]) and np.array_equal(a["hit_id"], b["hit_id"]), (depth, kw)
+        assert np.array_equal(a["rgb32f"].view(np.uint32), b["rgb32f"].view(np.uint32)), (depth, kw)
+        assert a["counters"]["rays"] == b["counters"]["rays"], (depth, kw)
+
+
 def test_wavefront_bands_do_not_change_the_image():
     """A tiny workspace budget forces the wavefront schedule to run the frame in bands."""
     m = CASES["c2_mount_low_256x144_d4_bvh"]
