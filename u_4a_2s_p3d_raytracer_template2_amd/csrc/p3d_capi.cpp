@@ -472,6 +472,11 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
         }
     }
     const unsigned resident_waves = s->wf_occ.waves;
+    // pair mode (LaunchParams::wf_pair_in): the last level combines sibling rays with their parent in registers, so
+    // level D - 1 needs no resolve launch
+    const bool pair_mode = D >= 2 && !getenv("P3D_NO_PAIR_MODE");
+    P.wf_pair_in = 0; P.wf_pair_out = (pair_mode && D == 2) ? 1 : 0;
+    P.wf_nodes_grand = nullptr; P.wf_ncap_grand = 0;
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], stream));
     HIP_TRY(launch_wf_primary(P, count, lds, walk, occ, stream));
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], stream));
@@ -482,23 +487,28 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
         P.wf_rng_in = rng(l); P.wf_rng_out = rng(l + 1);
         P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = cap(l - 1);
         P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
+        P.wf_pair_out = (pair_mode && l == D - 1) ? 1 : 0;
+        P.wf_pair_in = (pair_mode && l == D) ? 1 : 0;
+        P.wf_nodes_grand = l >= 3 ? nodes(l - 2) : nullptr; P.wf_ncap_grand = l >= 3 ? cap(l - 2) : 0;
         size_t total = (size_t)cap(l) * kShards;
         // LDS scenes: as many waves as can be resident (the kernel numbers its batches through all shards)
         unsigned waves = (unsigned)std::min<size_t>((total + 63) / 64, lds ? resident_waves : kPersistentWavesNarrow);
         waves = std::max<unsigned>(kShards * 4, (waves / (kShards * 4)) * (kShards * 4));   // whole workgroups per shard
         HIP_TRY(launch_wf_secondary(P, count, lds, walk, occ, waves, stream));
     }
-    if (D >= 3 && shard_px <= (size_t)s->fused_resolve_shard_px) {
+    P.wf_pair_in = P.wf_pair_out = 0;
+    const int top = pair_mode ? D - 2 : D - 1;            // highest level that still has to be resolved by a launch
+    if (top >= 2 && shard_px <= (size_t)s->fused_resolve_shard_px) {
         // small frame (a rank's share of a tiled frame): all resolve levels in ONE launch, a workgroup per shard
         ResolveLevels R;
         memset(&R, 0, sizeof R);
-        for (int l = 1; l <= D - 1; l++) { R.nodes[l] = nodes(l); R.ncount[l] = ncount(l); R.cap[l] = cap(l); }
-        R.top = D - 1;
+        for (int l = 1; l <= top; l++) { R.nodes[l] = nodes(l); R.ncount[l] = ncount(l); R.cap[l] = cap(l); }
+        R.top = top;
         P.wf_level = 1;
         HIP_TRY(launch_wf_resolve_fused(P, R, kShards, stream));
         return P3D_OK;
     }
-    for (int l = D - 1; l >= 1; l--) {
+    for (int l = top; l >= 1; l--) {
         P.wf_level = l;
         P.wf_nodes_self = nodes(l); P.wf_ncount_self = ncount(l); P.wf_ncap_self = cap(l);
         P.wf_nodes_parent = nodes(l - 1); P.wf_ncap_parent = l > 1 ? cap(l - 1) : 0;

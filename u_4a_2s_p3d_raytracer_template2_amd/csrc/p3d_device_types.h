@@ -70,6 +70,7 @@ struct RayRec { float o[3]; float ior; float d[3]; uint32_t link; };         // 
 struct NodeRec { float color[3]; float KR; float refl_ret[3]; uint32_t mat;
                  float refr_ret[3]; uint32_t link; };                        // 48 B
 constexpr uint32_t kLinkRefr = 0x80000000u;
+constexpr uint32_t kPairEmpty = 0x7FFFFFFFu;      // RayRec::link of the unused half of a sibling pair (LaunchParams::wf_pair_out)
 struct DeviceCounters {
     unsigned long long closest_queries, shadow_queries, box_tests, sphere_tests, tri_tests,
         aabox_tests, plane_tests, pixels;
@@ -131,6 +132,12 @@ struct LaunchParams {
     uint32_t* wf_alt; uint32_t* wf_ctrl;
     uint32_t dbg_skip;                // diagnostic builds only (P3D_DEBUG_SKIP): 1 = no shading after the closest hit, 2 = no shadow queries
     NodeRec* wf_nodes_parent;                                     // level wf_level - 1 nodes
+    // Last level of a pass ("pair mode"): the launch of level D - 1 queues the two children of a node in an even / odd
+    // slot pair (wf_pair_out; a missing child leaves a kPairEmpty slot), and the launch of level D (wf_pair_in) -- whose
+    // rays all return at once, RT/main.cpp:632-634 -- combines each pair with its parent's parked record in registers and
+    // hands the result to the GRANDPARENT (level D - 2 nodes, or the pixel): no resolve launch for level D - 1.
+    int32_t wf_pair_in, wf_pair_out;
+    NodeRec* wf_nodes_grand; uint32_t wf_ncap_grand;
     NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
     float* wf_planes; uint64_t wf_plane_stride;                   // [sample][local px][3] clamped sample colours; floats per plane
     int32_t wf_min_width;            // fewest lanes a deeper-level wave may use (64 = never narrow)

@@ -7,7 +7,8 @@
 //    children are parked as 48-byte NodeRec, their child rays are compacted into the next
 //    level's queue with wave ballot + mbcnt prefix sums (one atomic per wave), and resolve
 //    launches walk the levels back up combining children into parents in the reference's
-//    post-order arithmetic.  Every launch is short and uniform: no lane waits for a
+//    post-order arithmetic (the last level combines sibling pairs with their parent itself:
+//    combine_pair).  Every launch is short and uniform: no lane waits for a
 //    neighbour's deeper tree, there is no per-lane recursion stack, and the only LDS use is the
 //    BVH traversal stack.
 //  * TREE (P3D_FLAG_TREE_KERNEL, and the fallback when the worst-case queues would not fit):
@@ -120,6 +121,7 @@ struct Shard {
     const RayRec* rays_in; uint32_t count_in;
     RayRec* rays_out; uint32_t* count_out;
     NodeRec* nodes_parent; NodeRec* nodes_self; uint32_t* ncount_self;
+    NodeRec* nodes_grand;                          // level wf_level - 2 (pair mode)
     const uint32_t* rng_in; uint32_t* rng_out;     // random-stream keys of the queued rays, or nullptr
 };
 // the counter arrays of this launch under pass parity `par` (see LaunchParams::wf_alt)
@@ -140,6 +142,7 @@ __device__ __forceinline__ Shard shard_of(const LaunchParams& P, uint32_t s, uin
     h.count_out = count_out_array(P, par) + s;
     h.nodes_parent = P.wf_nodes_parent ? P.wf_nodes_parent + (size_t)s * P.wf_ncap_parent : nullptr;
     h.nodes_self = P.wf_nodes_self ? P.wf_nodes_self + (size_t)s * P.wf_ncap_self : nullptr;
+    h.nodes_grand = P.wf_nodes_grand ? P.wf_nodes_grand + (size_t)s * P.wf_ncap_grand : nullptr;
     h.ncount_self = ncount_self_array(P, par) + s;
     h.rng_in = P.wf_rng_in ? P.wf_rng_in + (size_t)s * P.wf_cap_in : nullptr;
     h.rng_out = P.wf_rng_out ? P.wf_rng_out + (size_t)s * P.wf_cap_out : nullptr;
@@ -167,10 +170,11 @@ __device__ __forceinline__ void emit(const LaunchParams& P, const Shard& sh, int
     const uint64_t m_refl = __ballot(parks && o.has_refl);
     const uint64_t m_refr = __ballot(parks && o.has_refr);
     const uint32_t n_refl = (uint32_t)__popcll(m_refl), n_refr = (uint32_t)__popcll(m_refr);
+    const bool pairs = P.wf_pair_out != 0;                     // sibling pairs in even / odd slots for the last level
     uint32_t node_base = 0, ray_base = 0;
     if (lane == (int)__builtin_ctzll(m_node)) {
         node_base = atomicAdd(sh.ncount_self, (uint32_t)__popcll(m_node));
-        ray_base = atomicAdd(sh.count_out, n_refl + n_refr);
+        ray_base = atomicAdd(sh.count_out, pairs ? 2u * (uint32_t)__popcll(m_node) : n_refl + n_refr);
     }
     node_base = __shfl(node_base, (int)__builtin_ctzll(m_node));
     ray_base = __shfl(ray_base, (int)__builtin_ctzll(m_node));
@@ -180,6 +184,17 @@ __device__ __forceinline__ void emit(const LaunchParams& P, const Shard& sh, int
     nd[0] = make_float4(o.color.x, o.color.y, o.color.z, o.KR);
     nd[1] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(o.mat));
     nd[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(link));
+    if (pairs) {
+        const uint32_t slot = ray_base + 2u * lane_rank(m_node);
+        float4* rq = reinterpret_cast<float4*>(sh.rays_out + slot);
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kPairEmpty));
+        rq[0] = o.has_refl ? make_float4(o.refl.o.x, o.refl.o.y, o.refl.o.z, ior_1) : z;
+        rq[1] = o.has_refl ? make_float4(o.refl.d.x, o.refl.d.y, o.refl.d.z, __uint_as_float(my_node)) : z;
+        rq[2] = o.has_refr ? make_float4(o.refr.o.x, o.refr.o.y, o.refr.o.z, o.newIor) : z;
+        rq[3] = o.has_refr ? make_float4(o.refr.d.x, o.refr.d.y, o.refr.d.z, __uint_as_float(my_node | kLinkRefr)) : z;
+        if (sh.rng_out) { sh.rng_out[slot] = o.rng_refl; sh.rng_out[slot + 1] = o.rng_refr; }
+        return;
+    }
     if (o.has_refl) {                                           // reflection child keeps ior_1
         const uint32_t slot = ray_base + lane_rank(m_refl);
         float4* rq = reinterpret_cast<float4*>(sh.rays_out + slot);
@@ -223,6 +238,30 @@ template <> struct View<true> {
     }
     static __device__ __forceinline__ uint32_t scene_dwords(const LaunchParams& P) { return P.blob_quads * 4; }
 };
+
+// Last level in pair mode (LaunchParams::wf_pair_in): every ray of the level has returned (o.ret), lanes 2k / 2k+1 hold
+// the reflection / refraction child of one level-(D-1) node.  The even lane combines them with the node's parked record
+// -- "color += reflection_color * KR * specColor + refraction_color * (1 - KR)", RT/main.cpp:719, a never-traced child
+// adds zero -- and hands the result one level further up.  Must be reached by all lanes of the wave together.
+__device__ __forceinline__ void combine_pair(const LaunchParams& P, const Shard& sh, bool valid, uint32_t link, const NodeOut& o) {
+    const int lane = threadIdx.x & 63;
+    const V3 mine = valid ? o.ret : mk(0.0f, 0.0f, 0.0f);
+    const V3 other = mk(__shfl_xor(mine.x, 1), __shfl_xor(mine.y, 1), __shfl_xor(mine.z, 1));
+    const uint32_t other_link = (uint32_t)__shfl_xor((int)link, 1);
+    const bool other_valid = __shfl_xor(valid ? 1 : 0, 1) != 0;
+    if ((lane & 1) != 0 || !(valid || other_valid)) return;
+    const uint32_t parent = (valid ? link : other_link) & ~kLinkRefr;
+    const GlobalScene gv = View<false>::make(P);
+    const float4* nd = reinterpret_cast<const float4*>(sh.nodes_parent + parent);
+    const float4 a = nd[0], b = nd[1], c = nd[2];
+    const Mtl M = load_material(gv, __float_as_uint(b.w));
+    const V3 ret = combine_node(mk(a.x, a.y, a.z), a.w, M.spec, mine, other);
+    const uint32_t up = __float_as_uint(c.w);
+    if (P.wf_level == 2) { sink_sample(P, (size_t)up, ret); return; }
+    NodeRec* g = sh.nodes_grand + (up & ~kLinkRefr);
+    float* dst = (up & kLinkRefr) ? g->refr_ret : g->refl_ret;
+    dst[0] = ret.x; dst[1] = ret.y; dst[2] = ret.z;
+}
 
 // this wave's traversal stack: after the (optional) scene copy, one region per wave
 template <bool LDS>
@@ -349,10 +388,12 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
                 ior_1 = a.w; link = __float_as_uint(bq.w);
                 if (STOCH) rng = sh.rng_in[i];
             }
-            const Hit h = find_closest<COUNT, WALK>(P, sv, ray, valid, tc, ctr);
-            const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, P.wf_level, ior_1, tc,
+            const bool live = valid && link != kPairEmpty;           // (the unused half of a sibling pair)
+            const Hit h = find_closest<COUNT, WALK>(P, sv, ray, live, tc, ctr);
+            const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
                                                                                     ctr, rng);
-            emit(P, sh, P.wf_level, valid, link, ior_1, o);
+            if (P.wf_pair_in) combine_pair(P, sh, live, link, o);
+            else emit(P, sh, P.wf_level, live, link, ior_1, o);
         }
         flush_counters<COUNT>(P, ctr, 0u);
         return;
@@ -387,10 +428,12 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
             ior_1 = a.w; link = __float_as_uint(b.w);
             if (STOCH) rng = sh.rng_in[i];
         }
-        const Hit h = find_closest<COUNT, WALK>(P, sv, ray, valid, tc, ctr);
-        const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, P.wf_level, ior_1, tc,
+        const bool live = valid && link != kPairEmpty;
+        const Hit h = find_closest<COUNT, WALK>(P, sv, ray, live, tc, ctr);
+        const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
                                                                                 ctr, rng);
-        emit(P, sh, P.wf_level, valid, link, ior_1, o);
+        if (P.wf_pair_in) combine_pair(P, sh, live, link, o);
+        else emit(P, sh, P.wf_level, live, link, ior_1, o);
     }
     flush_counters<COUNT>(P, ctr, 0u);
 }
