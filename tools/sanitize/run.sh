@@ -8,7 +8,7 @@ for f in $R/tests/golden/scenes/*.p3f.xz; do xz -dkc $f > $W/$(basename $f .xz);
 C=$R/u_4a_2s_p3d_raytracer_template2_amd/csrc
 SAN="-g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off"
 g++ $SAN -std=c++17 -I$C -I$R/include $R/tools/sanitize/host_main.cpp $C/host/p3d_scene.cpp $C/bvh_builder.cpp \
-    $C/scene_flatten.cpp -o $W/san_host -Wl,--unresolved-symbols=ignore-all
+    $C/scene_flatten.cpp $C/grid_builder.cpp -o $W/san_host -Wl,--unresolved-symbols=ignore-all
 g++ $SAN -std=c++14 -I$R/oracle $R/tools/sanitize/oracle_main.cpp $R/oracle/p3d_oracle.cpp $R/oracle/pt_oracle.cpp -lpthread -o $W/san_oracle
 cd $W
 ./san_host *.p3f
