@@ -74,6 +74,24 @@ __global__ __launch_bounds__(1024) void k(float* out, unsigned long long* cyc, f
                 lds[idx] = idx;
                 for (int q = 0; q < 8; q++) idx = lds[idx & 255];
                 a5 += (float)idx * 1e-30f;
+            } else if (KIND == 13) {  // 8 v_mul_f32 + 4 s_add_u32 interleaved in ONE wave (the 2:1 mix of the ray kernels)
+                unsigned s0 = it, s1 = it + 1;
+                asm volatile("v_mul_f32 %0, %0, %10\n v_mul_f32 %1, %1, %10\n s_add_u32 %8, %8, 3\n v_mul_f32 %2, %2, %10\n v_mul_f32 %3, %3, %10\n s_add_u32 %9, %9, 5\n"
+                             "v_mul_f32 %4, %4, %10\n v_mul_f32 %5, %5, %10\n s_add_u32 %8, %8, 3\n v_mul_f32 %6, %6, %10\n v_mul_f32 %7, %7, %10\n s_add_u32 %9, %9, 5\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1) : "v"(m) : "scc");
+                a0 += (float)(s0 + s1) * 1e-30f;
+            } else if (KIND == 14) {  // even waves: 8 v_mul_f32, odd waves: 8 s_add_u32 -- do vector and scalar issue of DIFFERENT waves overlap?
+                if (((threadIdx.x >> 6) & 1) == 0) {
+                    asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                                 "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+                } else {
+                    unsigned s0 = it, s1 = it + 1, s2 = it + 2, s3 = it + 3;
+                    asm volatile("s_add_u32 %0, %0, 3\n s_add_u32 %1, %1, 5\n s_add_u32 %2, %2, 7\n s_add_u32 %3, %3, 9\n"
+                                 "s_add_u32 %0, %0, 3\n s_add_u32 %1, %1, 5\n s_add_u32 %2, %2, 7\n s_add_u32 %3, %3, 9\n"
+                                 : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+                    a0 += (float)(s0 + s1 + s2 + s3) * 1e-30f;
+                }
             } else if (KIND == 7) {   // 8 v_cndmask
                 asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
                              "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
@@ -121,5 +139,7 @@ int main() {
     run<10>("cmp/saveexec/add/restore x4", 16);
     run<11>("v_readfirstlane x8 (+2 valu)", 8);
     run<12>("dependent ds_read_b32 x8", 8);
+    run<13>("8 v_mul + 4 s_add, one wave", 12);
+    run<14>("v_mul waves beside s_add waves", 8);
     return 0;
 }
