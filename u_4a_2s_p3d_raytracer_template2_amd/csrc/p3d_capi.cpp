@@ -567,8 +567,11 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     }
     P.n_planes = s->stats.n_planes; P.n_lights = s->n_lights; P.n_materials = s->n_materials;
     P.trav_stack_entries = std::max<uint32_t>(s->stats.max_depth + 1, 2);
-    // 8-byte slots for LDS-resident scenes, 4-byte slots for scenes read from HBM (p3d_traverse.h)
-    P.trav_stack_dwords = P.trav_stack_entries * (lds_scene ? 128u : kHbmStackDwordsPerEntry);
+    // 4-byte slots (node references only, p3d_traverse.h) for both scene placements
+#ifndef P3D_LDS_STACK_DWORDS
+#define P3D_LDS_STACK_DWORDS 64u      // RefStack: 4-byte slots (WideStack: 128)
+#endif
+    P.trav_stack_dwords = P.trav_stack_entries * (lds_scene ? P3D_LDS_STACK_DWORDS : kHbmStackDwordsPerEntry);
     memcpy(P.bg, s->bg, sizeof P.bg);
     memcpy(P.eye, cam->eye, sizeof P.eye); memcpy(P.u, cam->u, sizeof P.u);
     memcpy(P.v, cam->v, sizeof P.v); memcpy(P.n, cam->n, sizeof P.n);

@@ -92,8 +92,8 @@ template <class SV> __device__ __forceinline__ void sv_mat(const SV& sv, uint32_
 // A lane's traversal stack lives in its wave's LDS region, laid out [slot][lane].  An entry is a
 // node ref plus the ray's entry distance into that node (popped entries farther than the best hit
 // are skipped without touching memory).  Two layouts behind one interface:
-//  WideStack  8-byte entries {ref, t as f32}: one ds_write_b64 / ds_read_b64.  Scenes rendered from
-//             an LDS copy -- their trees are a few levels deep and the kernels are issue-bound.
+//  WideStack  (the LDS-scene stack until late in round 2, kept for comparison builds) 8-byte entries {ref, t as f32}:
+//             one ds_write_b64 / ds_read_b64, popped entries farther than the best hit skipped in a loop.
 //  SlimStack  (round 1; superseded by RefStack below, kept for comparison builds: -DP3D_HBM_STACK=SlimStack
 //             -DP3D_HBM_STACK_DWORDS=96u) 6-byte entries: refs in one [slot][lane] plane, t truncated to its upper
 //             16 bits in a second one.  Scenes read from HBM -- a depth-25 stack is 12.8 KB per wave wide, 9.6 KB
@@ -170,7 +170,13 @@ struct RefStack {
 #define P3D_HBM_STACK RefStack
 #endif
 template <class SV> struct StackOf;
-template <> struct StackOf<LdsScene> { typedef WideStack type; };
+// scenes in LDS: reference-only slots too since round 2 (the pruning pop loop of WideStack compiled to ~25 scalar
+// instructions per pop; without it the level-1 kernel runs 377 -> 360 SALU per wave, config 2 0.1279 -> 0.1263 ms,
+// config 4 4.91 -> 4.81 ms); comparison build: -DP3D_LDS_STACK=WideStack -DP3D_LDS_STACK_DWORDS=128u
+#ifndef P3D_LDS_STACK
+#define P3D_LDS_STACK RefStack
+#endif
+template <> struct StackOf<LdsScene> { typedef P3D_LDS_STACK type; };
 template <> struct StackOf<GlobalScene> { typedef P3D_HBM_STACK type; };
 
 struct SlabRay { float kx, ky, kz, ix, iy, iz; };     // i = 1/d, k = -o/d: a plane's distance is fma(plane, i, k)
@@ -217,7 +223,10 @@ __device__ __forceinline__ bool slab(const SlabRay& s, float lx, float ly, float
     float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     t1 = t1 * 1.0000005f + 1e-30f;
     tn = t0;
-    return (t0 <= t1) && (t1 >= 0.0f) && (t0 <= tlimit);
+    // (t0 <= t1 && t0 <= tlimit) as ONE comparison against min(t1, tlimit): a mask AND on the scalar unit less per child.
+    // t0 itself stays in the comparison, so a ray with NaNs in it (t0 and t1 both NaN) still misses every box -- folding
+    // t1 >= 0 in as max(t0, 0) would not: fmax drops the NaN (profiles/r02_experiments_traversal.txt).
+    return (t0 <= fminf(t1, tlimit)) && (t1 >= 0.0f);
 }
 
 // One visit of node pair `n`: both children's slab tests (hit flags, entry distances) and their references.
