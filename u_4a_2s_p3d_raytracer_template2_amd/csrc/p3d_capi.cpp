@@ -810,8 +810,8 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));
         P.wf_tile_row0 = 0; P.wf_tile_rows = P.tiles_y;
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
-        // scenes read from HBM: a register budget of 5 waves per SIMD (dragon 1.58 -> 1.54 ms; 6 spills too much: 1.57)
-        HIP_TRY(launch_tree(P, count, lds_scene, s->occupancy ? s->occupancy : (lds_scene ? 0 : 5), s->stream));
+        // scenes read from HBM: a register budget of 6 waves per SIMD (dragon with the flat walk loop: 1.285 ms at 5, 1.239 at 6)
+        HIP_TRY(launch_tree(P, count, lds_scene, s->occupancy ? s->occupancy : (lds_scene ? 0 : 6), s->stream));
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream));
     } else {
         // a shard owns every kShards-th tile of the band
