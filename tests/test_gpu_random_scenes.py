@@ -96,3 +96,24 @@ def test_rays_with_a_zero_direction_component(tmp_path):
                dict(tree=True, no_lds=True), dict(tile=True, no_lds=True), dict(wavefront=True, packet=True)):
         check(path, 2, 4, **kw)
     check(path, 0, 3, wavefront=True, no_lds=True)
+
+
+def test_rays_with_nan_components(tmp_path):
+    """A glass sphere hit exactly head-on (camera on an axis, odd resolution, sphere centred on that axis): the view
+    tangent is the zero vector, the reference's normalize() makes it NaN, and the refraction ray is NaN in every
+    component.  Such a ray must miss every box of the tree at once -- the slab test's ordered comparisons
+    see to that -- and the pixel must come out as in the oracle, on both node formats and every schedule."""
+    L = ["accel 2", "spp 0", "bclr 0.1 0.3 0.6", "v", "from 0 0 5", "at 0 0 0", "up 0 1 0", "angle 30",
+         "hither 0.01", "resolution 33 33", "aperture 0", "focal 1", "l 3 4 8 1 1 1",
+         "f 0.9 0.9 1 0.1 1 1 1 0.3 60 1 1.5", "s 0 0 0 0.8",
+         "f 0.8 0.5 0.3 0.9 1 1 1 0 10 0 1", "s 0.5 0.4 -2 0.6", "s -0.7 -0.3 -2.5 0.5",
+         "p 3\n-3 -3 -4\n3 -3 -4\n0 3 -4"]
+    path = str(tmp_path / "headon.p3f")
+    open(path, "w").write("\n".join(L) + "\n")
+    sc = O.Scene(path)
+    ref = sc.render(max_depth=4, accel=2)
+    assert ref["hit_id"][16, 16] == 0                                  # the centre pixel does hit the glass sphere
+    for kw in (dict(wavefront=True), dict(tile=True), dict(tree=True), dict(wavefront=True, no_lds=True),
+               dict(tree=True, no_lds=True), dict(tile=True, no_lds=True)):
+        check(path, 2, 4, **kw)
+        check(path, 0, 3, **kw)
