@@ -13,8 +13,10 @@ hs = P.HostScene(scene_path("mount_low")); hs.set_resolution(res, res); cam = hs
 t0 = time.time(); samples = hs.samples(12345, 2); t1 = time.time()
 print("sample stream: %.2f s on the host, %.0f MB" % (t1 - t0, samples.nbytes / 1e6))
 ds = P.DeviceScene.from_host(hs)
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and int(sys.argv[2]) > 0:
     ds.set_tuning(workspace_mib=int(sys.argv[2]))          # workspace budget in MiB (default 65536)
+if len(sys.argv) > 3:
+    ds.set_tuning(waves_per_simd=int(sys.argv[3]))         # register budget of the ray kernels: 0 default, 5, 6
 out = torch.zeros((res, res, 3), dtype=torch.uint8, device="cuda")
 kw = dict(max_depth=6, accel=P.ACCEL_BVH, spp=2, samples=samples)
 ds.render_device(cam, rgb8_ptr=out.data_ptr(), counters=True, **kw)
