@@ -185,6 +185,8 @@ struct p3d_scene {
     int frame_streams = 1;               // bands of a one-sample frame run concurrently on this many streams (experiment knob)
     int resolve_blocks_per_shard = 16;   // a resolve launch is latency-bound: few nodes per thread, many threads
     int fused_resolve_shard_px = 8192;   // frames with at most this many pixels per shard resolve all levels in one launch
+    bool pair_mode = true;               // the last level combines sibling rays with their parent (LaunchParams::wf_pair_in)
+    uint32_t dbg_skip = 0;               // diagnostic builds only (LaunchParams::dbg_skip)
     unsigned long long* dbg_stamps = nullptr;
     int occupancy = 0;     // 0 = compiler default register budget, else 5 / 6 / 8 waves per SIMD
 };
@@ -294,6 +296,8 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     if (const char* e = getenv("P3D_FRAME_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= kLanes) s->frame_streams = v; }
     if (const char* e = getenv("P3D_RESOLVE_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 64) s->resolve_blocks_per_shard = v; }   // tuning experiments
     if (const char* e = getenv("P3D_FUSED_RESOLVE_PX")) s->fused_resolve_shard_px = atoi(e);
+    s->pair_mode = getenv("P3D_NO_PAIR_MODE") == nullptr;
+    if (const char* e = getenv("P3D_DEBUG_SKIP")) s->dbg_skip = (uint32_t)atoi(e);      // read by -DP3D_DEBUG_SKIP builds only
     auto bail = [&](hipError_t e, const char* what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(e);
         p3d_scene_destroy(s);
@@ -474,7 +478,7 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
     const unsigned resident_waves = s->wf_occ.waves;
     // pair mode (LaunchParams::wf_pair_in): the last level combines sibling rays with their parent in registers, so
     // level D - 1 needs no resolve launch
-    const bool pair_mode = D >= 2 && !getenv("P3D_NO_PAIR_MODE");
+    const bool pair_mode = D >= 2 && s->pair_mode;
     P.wf_pair_in = 0; P.wf_pair_out = (pair_mode && D == 2) ? 1 : 0;
     P.wf_nodes_grand = nullptr; P.wf_ncap_grand = 0;
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], stream));
@@ -598,7 +602,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         P.grid_blocks = ((chunks + 7) / 8) * 8 * P.xcd_chunk;
     }
     P.counters = s->d_counters;
-    if (const char* e = getenv("P3D_DEBUG_SKIP")) P.dbg_skip = (uint32_t)atoi(e);      // read by -DP3D_DEBUG_SKIP builds only
+    P.dbg_skip = s->dbg_skip;
     P.dbg_stamps = s->dbg_stamps;
     P.wf_min_width = lds_scene ? 64 : 8;
 
