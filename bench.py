@@ -9,6 +9,9 @@ Workloads (--workload):
              A step = --frames-per-step frames into HBM-resident buffers, --frames-in-flight of them overlapped
              (independent frames on separate scene handles / HIP streams, like the reference's render-another-
              image loop).
+  config3    dragon.p3f (100 005 primitives) 1920x1080 depth 4 BVH (BASELINE config 3): every primitive is
+             traversed, like in the reference; the cull_never_hit build is timed beside it and reported as a
+             second figure (config.cull_never_hit), never as `value`.  CPU baseline at 128x128.
   config4    mount_low.p3f 4096x4096 depth 6, 2x2 jittered samples + thin lens (BASELINE config 4): one frame per
              step, the sample array uploaded once.
   synthetic  the SURVEY 8d scaling scene (--prims random spheres + triangles, BVH read from HBM).
@@ -22,17 +25,30 @@ set).  torch.distributed (gloo) only carries the 128-byte communicator id, the b
 value = rays of all frames / max-over-ranks wall time; a ray is one closest-hit or one shadow query,
 counted by the counting build of the same kernels on the same frame.
 
+The line checks what it timed:
+  "frame_matches_reference"  the LAST TIMED FRAME (device buffer, downloaded after the timed region) equals the
+                 frame the cpu_baseline leg rendered -- by the reference's own object code where that renders the
+                 same frame (config 2), else by the oracle port on all cores at full size, with the reference's
+                 frame at the sample resolution compared against a GPU frame of that resolution; rgb8 equal except
+                 for at most U8_EXCEPTIONS_PER_MVALUE values per 10^6 one level off (ROCm's powf vs glibc's, last
+                 bit; measured 0 on every frame so far) and equal ray counts.  Details in "frame_check".
+  "gather_verified"  (N > 1) the gathered, de-interleaved frame on rank 0 equals a one-GPU render of the same frame.
+
 Extra objects on the JSON line:
-  "roofline"     for the ray kernel with the most device time (from the rocprofv3 kernel stats committed under
-                 profiles/, see profiles/current.json).  The 12-primitive scene lives in LDS, so HBM is not what
-                 binds these kernels: the bound is VECTOR-INSTRUCTION ISSUE (one wave-instruction per 2 cycles per
-                 SIMD, measured: profiles/r02_valu_rate_ubench.txt); achieved = SQ_INSTS_VALU per launch / its
-                 duration.  Scalar-unit load, the SURVEY 8d algorithmic-bytes figure and the PMC-measured HBM
-                 traffic are reported next to it.  Every number can be recomputed from the files named in
-                 roofline.source; roofline.kernel_ms_live is this run's own HIP-event duration of that kernel.
+  "roofline"     for the ray kernel with the most device time (from the rocprofv3 kernel stats and PMC summaries
+                 committed under profiles/, see profiles/current.json).  bound "valu_issue" for scenes served from
+                 LDS (config 2 / 4: HBM is not what binds a 12-primitive scene): achieved = SQ_INSTS_VALU per launch
+                 / its duration against one wave-instruction per 2 cycles per SIMD (measured:
+                 profiles/r02_valu_rate_ubench.txt).  bound "fetch_latency" for scenes read from HBM (config 3,
+                 synthetic): those kernels reach neither the issue nor the HBM roof, they wait on dependent
+                 fetches -- the object carries lanes active, SQ_WAIT_ANY / SQ_WAVE_CYCLES, L1 / L2 hit rates, L2 and
+                 fabric GB/s against their peaks, and the same vector-issue fraction (= achieved / peak / frac).
+                 Every number can be recomputed from the files named in roofline.source;
+                 roofline.kernel_ms_live is this run's own HIP-event duration of the dominant launch.
   "cpu_baseline" at N = 1: the REFERENCE's own object code (oracle/_ref, built from /root/reference in the build
                  container and carried as a .so) rendering whole frames of the same configuration on one host
                  core -- the reference is single-threaded; the oracle port on all cores is reported beside it.
+  "env"          the library that was loaded and every P3D_* environment variable that was set.
 """
 import argparse
 import hashlib
@@ -48,18 +64,25 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+L2_PEAK_GBS = 34500.0            # aggregate L2 bandwidth (MI355X_MICROARCH.md, "L2 (per XCD)")
 CLOCK_GHZ = 2.4                  # max shader clock (MI355X_MICROARCH.md)
 N_SIMD, N_CU = 1024, 256
 VALU_CYCLES_PER_INST = 2.0       # one wave64 VALU instruction per 2 cycles per SIMD (measured, ubench)
 ROW_BLOCK = 16
+# rgb8 values per 10^6 that may be ONE level off the reference's: ROCm's powf and glibc's differ in the last bit on a
+# fraction of inputs, and a colour exactly on a quantisation step can then land on the other side.  Measured: 0.
+U8_EXCEPTIONS_PER_MVALUE = 1
 
 WORKLOADS = {
     "config2": dict(scene="mount_low", res=(1920, 1080), depth=4, spp=0, frames=12,
                     name="mount_low.p3f 1920x1080 depth 4 BVH (BASELINE config 2)"),
+    "config3": dict(scene="dragon", res=(1920, 1080), depth=4, spp=0, frames=4, cpu_res=(128, 128),
+                    name="dragon.p3f (100 005 primitives) 1920x1080 depth 4 BVH (BASELINE config 3)"),
     "config4": dict(scene="mount_low", res=(4096, 4096), depth=6, spp=2, frames=1, cpu_res=(1024, 1024),
                     name="mount_low.p3f 4096x4096 depth 6, 2x2 samples + thin lens (BASELINE config 4)"),
     "synthetic": dict(scene=None, res=(1920, 1080), depth=4, spp=0, frames=12, name=None),
 }
+HBM_SCENE_WORKLOADS = ("config3", "synthetic")      # scenes the kernels read from HBM / L2, not from an LDS copy
 
 
 def kernel_source_digest():
@@ -72,24 +95,46 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(scene_file, res, depth, spp, budget_s=20.0):
-    """Whole frames of the configuration on ONE host core by the reference's own object code (oracle/_ref);
-    the oracle port (same structure, checked bit for bit against it) when the .so did not travel.  Plus the
-    oracle with the fall-through removed on all cores.  Checker-only code: never on the product path."""
+def host_threads():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def compare_u8(a, b):
+    """rgb8 planes: equal up to U8_EXCEPTIONS_PER_MVALUE one-level exceptions per 10^6 values (see above)."""
+    if a.shape != b.shape:
+        return {"values": int(a.size), "match": False, "note": "shapes differ: %s vs %s" % (a.shape, b.shape)}
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    n = int(np.count_nonzero(d))
+    allowed = max(1, (a.size * U8_EXCEPTIONS_PER_MVALUE) // 1000000)
+    mx = int(d.max()) if d.size else 0
+    return {"values": int(a.size), "differing": n, "max_level_diff": mx, "allowed_one_level_exceptions": int(allowed),
+            "match": bool(mx <= 1 and n <= allowed)}
+
+
+def cpu_baseline(scene_file, full_res, cpu_res, depth, spp, budget_s=25.0, full_size_port=True):
+    """Frames of the configuration on ONE host core by the reference's own object code (oracle/_ref) at `cpu_res`
+    (the full frame for config 2, a bounded sample otherwise); the oracle port (same structure, checked bit for bit
+    against it) when the .so did not travel.  Plus the oracle with the fall-through removed on all cores at FULL
+    size.  Checker-only code: never on the product path.
+    Returns (cpu_baseline object, frames) with frames = {"sample": rgb8 at cpu_res + its ray count + who rendered it,
+    "full": rgb8 at full_res by the all-core port, or None}."""
     from oracle import oracle_py as O
     from oracle import ref_py as R
     sc = O.Scene(scene_file)
-    sc.set_resolution(*res)
-    times, rays, kind = [], 0, "port"
+    sc.set_resolution(*cpu_res)
+    times, rays, kind, frame = [], 0, "port", None
     t_start = time.time()
     if R.available(depth):
         kind = "reference"
-        rs = R.RefScene.from_oracle_scene(sc, scene_file, res=res, depth=depth)
+        rs = R.RefScene.from_oracle_scene(sc, scene_file, res=cpu_res, depth=depth)
         while len(times) < 5 and (time.time() - t_start) < budget_s * 0.6:
             t0 = time.perf_counter()
             r = rs.render(2, spp, 12345)
             times.append(time.perf_counter() - t0)
-            rays = r["rays"]
+            rays, frame = r["rays"], r["rgb8"]
             if times[-1] > budget_s * 0.3:
                 break
         rs.close()
@@ -98,27 +143,35 @@ def cpu_baseline(scene_file, res, depth, spp, budget_s=20.0):
             t0 = time.perf_counter()
             r = sc.render(max_depth=depth, accel=2, spp=spp, threads=1, want_f32=False, want_hit=False)
             times.append(time.perf_counter() - t0)
-            rays = r["counters"]["rays"]
+            rays, frame = r["counters"]["rays"], r["rgb8"]
             if times[-1] > budget_s * 0.3:
                 break
     st = float(np.median(times))
+    who = "the reference's own object code (oracle/_ref)" if kind == "reference" else "the oracle port"
     out = {"value": rays / st / 1e6, "unit": "Mrays/s", "cores": 1, "kind": kind,
-           "sample": "%d full %dx%d depth-%d%s frame(s) on one core by %s (BVH traversal + the brute-force "
+           "sample": "%d %s %dx%d depth-%d%s frame(s) on one core by %s (BVH traversal + the brute-force "
                      "fall-through of SURVEY Q1); median %.3f s/frame" % (
-                         len(times), res[0], res[1], depth, " spp %d" % spp if spp else "",
-                         "the reference's own object code (oracle/_ref)" if kind == "reference" else "the oracle port", st)}
-    if spp == 0:
-        ncpu = os.cpu_count() or 1
-        mt = []
-        while len(mt) < 3 and (time.time() - t_start) < budget_s:
+                         len(times), "full" if tuple(cpu_res) == tuple(full_res) else "reduced-size", cpu_res[0], cpu_res[1], depth,
+                         " spp %d" % spp if spp else "", who, st)}
+    frames = {"sample": {"rgb8": frame, "rays": int(rays), "res": tuple(cpu_res), "by": who}, "full": None}
+    if full_size_port:
+        ncpu = 1 if spp else host_threads()      # spp > 0 consumes libc rand() in pixel order: the port renders it on one thread
+        sc.set_resolution(*full_res)
+        mt, full, full_rays = [], None, 0
+        t_mt = time.time()
+        while len(mt) < 3 and (not mt or (time.time() - t_mt) + mt[-1] < budget_s * 0.5):
             t0 = time.perf_counter()
-            sc.render(max_depth=depth, accel=2, threads=ncpu, break_fixed=1, want_f32=False, want_hit=False)
+            r = sc.render(max_depth=depth, accel=2, spp=spp, threads=ncpu, break_fixed=1, want_f32=False, want_hit=False)
             mt.append(time.perf_counter() - t0)
-        if mt:
-            m = float(np.median(mt))
-            out["multithread"] = {"value": rays / m / 1e6, "unit": "Mrays/s", "cores": ncpu, "kind": "port",
-                                  "note": "oracle port, fall-through removed + row blocks over all host cores; median %.4f s/frame" % m}
-    return out
+            full, full_rays = r["rgb8"], r["counters"]["rays"]
+        m = float(np.median(mt))
+        out["multithread"] = {"value": full_rays / m / 1e6, "unit": "Mrays/s", "cores": ncpu, "kind": "port",
+                              "note": "oracle port, fall-through removed%s, full %dx%d frame; median %.4f s/frame"
+                                      % (" + row blocks over all host cores" if ncpu > 1 else " (one thread: serial rand() stream)", full_res[0], full_res[1], m)}
+        frames["full"] = {"rgb8": full, "rays": int(full_rays), "res": tuple(full_res),
+                          "by": "the oracle port with the fall-through removed (bit-identical to the reference's frame "
+                                "where both were run: tests/test_oracle_pinned.py), %d threads" % ncpu}
+    return out, frames
 
 
 def cpu_baseline_synthetic(n_prims, depth, budget_s=25.0):
@@ -126,7 +179,7 @@ def cpu_baseline_synthetic(n_prims, depth, budget_s=25.0):
     a 96x54 frame (1/400 of the pixels) of the same scene.  Only up to 2e5 primitives (.p3f text)."""
     if n_prims > 200000:
         return {"value": None, "unit": "Mrays/s", "cores": 1, "kind": "port",
-                "sample": "not run: the oracle loads .p3f text and its reference-structure closest hit is O(N) per ray"}
+                "sample": "not run: the oracle loads .p3f text and its reference-structure closest hit is O(N) per ray"}, None
     import tempfile
     from oracle import oracle_py as O
     from u_4a_2s_p3d_raytracer_template2_amd import synthetic as SY
@@ -136,8 +189,41 @@ def cpu_baseline_synthetic(n_prims, depth, budget_s=25.0):
     t0 = time.perf_counter()
     r = sc.render(max_depth=depth, accel=2, threads=1, want_f32=False, want_hit=False)
     st = time.perf_counter() - t0
-    return {"value": r["counters"]["rays"] / st / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": "one 96x54 depth-%d frame of the same scene, single thread, reference structure; %.2f s" % (depth, st)}
+    who = "the oracle port (reference structure)"
+    return ({"value": r["counters"]["rays"] / st / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+             "sample": "one 96x54 depth-%d frame of the same scene, single thread, reference structure; %.2f s" % (depth, st)},
+            {"sample": {"rgb8": r["rgb8"], "rays": int(r["counters"]["rays"]), "res": (96, 54), "by": who}, "full": None})
+
+
+def frame_check(frames, timed_frame, timed_rays, render_sample):
+    """Compare the last timed frame (and, where the CPU leg rendered a reduced-size sample, a GPU frame of that size
+    made by render_sample(res) -> (rgb8, rays)) with what the CPU leg rendered.  Returns (bool, details)."""
+    out, ok = {}, True
+    tol = "rgb8 equal except for <= %d value(s) per 10^6 one level off (powf last bit; measured 0); ray counts equal" % U8_EXCEPTIONS_PER_MVALUE
+    smp, full = frames.get("sample"), frames.get("full")
+    if smp is not None and tuple(smp["res"]) == (timed_frame.shape[1], timed_frame.shape[0]):
+        c = compare_u8(timed_frame, smp["rgb8"])
+        c.update({"against": smp["by"], "rays_gpu": int(timed_rays), "rays_cpu": smp["rays"], "rays_match": int(timed_rays) == smp["rays"]})
+        out["timed_frame"] = c
+        ok = ok and c["match"] and c["rays_match"]
+        smp = None
+    elif full is not None:
+        c = compare_u8(timed_frame, full["rgb8"])
+        c.update({"against": full["by"], "rays_gpu": int(timed_rays), "rays_cpu": full["rays"], "rays_match": int(timed_rays) == full["rays"]})
+        out["timed_frame"] = c
+        ok = ok and c["match"] and c["rays_match"]
+    else:
+        out["timed_frame"] = {"match": None, "note": "no CPU frame of the timed size"}
+    if smp is not None:
+        g8, grays = render_sample(smp["res"])
+        c = compare_u8(g8, smp["rgb8"])
+        c.update({"against": smp["by"], "res": list(smp["res"]), "rays_gpu": int(grays), "rays_cpu": smp["rays"], "rays_match": int(grays) == smp["rays"]})
+        out["reference_sample"] = c
+        ok = ok and c["match"] and c["rays_match"]
+    if out["timed_frame"].get("match") is None and "reference_sample" not in out:
+        return None, out
+    out["tolerance"] = tol
+    return bool(ok), out
 
 
 def _kname(name):
@@ -170,17 +256,23 @@ def load_profile(workload):
     return cur, stats, pmc
 
 
-def roofline_from_profiles(workload, live):
+def roofline_from_profiles(workload, live, profile_key=None):
     """The roofline object: see the module docstring.  `live` = this run's own measurements."""
-    cur, stats, pmc = load_profile(workload)
-    out = {"bound": "valu_issue", "achieved": None, "peak": N_SIMD * CLOCK_GHZ / VALU_CYCLES_PER_INST, "unit": "Gwave-instr/s",
-           "frac": None, "traffic": None, "kernel": live.get("kernel"), "kernel_ms_live": live.get("kernel_ms"),
+    cur, stats, pmc = load_profile(profile_key or workload)
+    hbm_scene = workload in HBM_SCENE_WORKLOADS
+    alg_note = ("SURVEY 8d: 32 B per slab test + 16/48/32/16 B per sphere/triangle/box/plane test + 3 B per pixel, counted by the "
+                "counting build; ")
+    alg_note += ("the walk is served by L1 / L2 / Infinity Cache, so this is NOT HBM traffic (roofline.hbm is): these kernels wait on "
+                 "dependent fetches" if hbm_scene else
+                 "the scene is served from LDS/L2, so this is NOT HBM traffic and HBM is not the binding resource")
+    out = {"bound": "fetch_latency" if hbm_scene else "valu_issue", "achieved": None,
+           "peak": N_SIMD * CLOCK_GHZ / VALU_CYCLES_PER_INST, "unit": "Gwave-instr/s",
+           "frac": None, "frac_of": "vector-instruction issue (one wave64 VALU instruction per 2 cycles per SIMD)",
+           "traffic": None, "kernel": live.get("kernel"), "kernel_ms_live": live.get("kernel_ms"),
            "frame_device_ms_live": live.get("frame_ms"),
            "algorithmic": {"bytes_per_frame": live.get("alg_bytes"), "GBps": live.get("alg_gbps"),
                            "frac_of_hbm_peak": None if live.get("alg_gbps") is None else live["alg_gbps"] / HBM_PEAK_GBS,
-                           "note": "SURVEY 8d: 32 B per slab test + 16/48/32/16 B per sphere/triangle/box/plane test + 3 B per pixel, "
-                                   "counted by the counting build; the scene is served from LDS/L2, so this is NOT HBM traffic and "
-                                   "HBM is not the binding resource"},
+                           "note": alg_note},
            "source": None, "stale": None}
     if not (cur and stats and pmc):
         out["note"] = "no profile registered in profiles/current.json for this workload: only live HIP-event timings"
@@ -223,6 +315,26 @@ def roofline_from_profiles(workload, live):
                 "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch_corrected"),
                 "kernel_cycles": cyc,
             })
+            if e.get("SQ_WAVE_CYCLES"):
+                # what a kernel that waits on fetches is bound by.  SQ_WAVE_CYCLES / SQ_WAIT_ANY count in units of 4 cycles
+                # (calibrated on the persistent tile kernel of config 4: 4 resident waves per SIMD read 0.85 x 4 that way)
+                f = {"wait_frac": e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"] if e.get("SQ_WAIT_ANY") else None,
+                     "waves_per_simd_avg": e["SQ_WAVE_CYCLES"] * 4.0 / (N_SIMD * cyc),
+                     "vmem_per_wave": e["SQ_INSTS_VMEM"] / e["SQ_WAVES"] if e.get("SQ_INSTS_VMEM") and e.get("SQ_WAVES") else None}
+                if e.get("TCC_REQ_sum"):
+                    f["l2_hit"] = e["TCC_HIT_sum"] / max(e["TCC_HIT_sum"] + e["TCC_MISS_sum"], 1.0)
+                if e.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                    f["l1_hit"] = 1.0 - e["TCP_TCC_READ_REQ_sum"] / e["TCP_TOTAL_CACHE_ACCESSES_sum"]
+                    f["l1_accesses_per_vmem"] = e["TCP_TOTAL_CACHE_ACCESSES_sum"] / e["SQ_INSTS_VMEM"] if e.get("SQ_INSTS_VMEM") else None
+                    f["l1_pending_stall_frac"] = e["TCP_PENDING_STALL_CYCLES_sum"] / (N_CU * cyc)
+                    f["l2_read_GBps"] = e["TCP_TCC_READ_REQ_sum"] * 64.0 / (avg_us * 1e-6) / 1e9      # 64-B requests
+                    f["l2_frac_of_peak"] = f["l2_read_GBps"] / L2_PEAK_GBS
+                    if e.get("TCP_TCC_READ_REQ_LATENCY_sum") and e.get("TCP_TCC_READ_REQ_sum"):
+                        f["l2_read_latency_cycles"] = e["TCP_TCC_READ_REQ_LATENCY_sum"] / e["TCP_TCC_READ_REQ_sum"]
+                if k["hbm_bytes_per_launch"]:
+                    f["fabric_GBps"] = k["hbm_bytes_per_launch"] / (avg_us * 1e-6) / 1e9
+                    f["fabric_frac_of_hbm_peak"] = f["fabric_GBps"] / HBM_PEAK_GBS
+                k["fetch"] = f
         kernels[_kname(name)] = k
     out["kernels"] = kernels
     tk = kernels[_kname(top["Name"])]
@@ -235,7 +347,14 @@ def roofline_from_profiles(workload, live):
         if out["traffic"]:
             out["hbm"] = {"GBps": out["traffic"] / (tk["avg_us"] * 1e-6) / 1e9,
                           "frac_of_hbm_peak": out["traffic"] / (tk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                          "note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch (gfx950 correction, separate passes): frame buffer + ray / node queues"}
+                          "note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch (gfx950 correction, separate passes)"
+                                  + (": node / primitive fetches that miss L2 + frame buffer" if hbm_scene else ": frame buffer + ray / node queues")}
+        if hbm_scene and tk.get("fetch"):
+            out["fetch_latency"] = dict(tk["fetch"], lanes_active=tk.get("lane_utilisation"), valu_issue_frac=tk.get("valu_issue_frac"),
+                                        salu_issue_frac=tk.get("salu_issue_frac"),
+                                        note="what binds a kernel that reads the scene from HBM / L2: the dependent fetch chain of the walk "
+                                             "(lanes active, share of wave-cycles spent waiting, cache hit rates, L2 and fabric rates against "
+                                             "their peaks); neither the vector-issue nor the HBM roof is near")
     return out
 
 
@@ -304,8 +423,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["config2", "config4", "pathtracer", "synthetic"], default="config2")
-    ap.add_argument("--frames-per-step", type=int, default=0, help="frames of a step (default: 12, config4: 1)")
+    ap.add_argument("--workload", choices=["config2", "config3", "config4", "pathtracer", "synthetic"], default="config2")
+    ap.add_argument("--frames-per-step", type=int, default=0, help="frames of a step (default: 12, config3: 4, config4: 1)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frames overlapped on separate HIP streams (each with its own scene handle and "
                          "workspace); 1 = strictly one frame after the other; default min(frames per step, 3 x N)")
@@ -313,7 +432,7 @@ def main():
                     help="replay the frames of a step as ONE captured HIP graph (auto = off: measured slower than eager launches)")
     ap.add_argument("--gather", choices=["pipelined", "sync"], default="pipelined",
                     help="N > 1: two tile-buffer sets, so that a step's gather overlaps the next step's rendering, or one")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (and with it frame_matches_reference)")
     ap.add_argument("--prims", type=int, default=1000000, help="synthetic workload: number of primitives")
     ap.add_argument("--schedule", choices=["default", "wavefront", "tree", "tile"], default="default",
                     help="force a kernel schedule (default: the library's measured choice)")
@@ -326,6 +445,7 @@ def main():
     import torch.distributed as dist
     from conftest import scene_path
     import u_4a_2s_p3d_raytracer_template2_amd as P
+    from u_4a_2s_p3d_raytracer_template2_amd import multigpu as MG
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -507,13 +627,8 @@ def main():
         if world > 1:
             comm_stream.wait_stream(main_stream)
             if host_gather:
-                torch.cuda.synchronize()
-                src = tile_sets[buf].cpu()
-                dst = list(torch.zeros((world,) + tuple(src.shape), dtype=torch.uint8).unbind(0)) if rank == 0 else None
-                dist.gather(src, gather_list=dst, dst=0)
-                if rank == 0:
-                    with torch.cuda.stream(comm_stream):
-                        gathered_sets[buf].copy_(torch.stack(dst))
+                MG.gather_tiles_through_host(tile_sets[buf], gathered_sets[buf] if rank == 0 else None, dist, rank, world,
+                                             torch, comm_stream)
             else:
                 comm.gather(gh, tile_sets[buf].data_ptr(), gathered_sets[buf].data_ptr() if rank == 0 else 0, B * tile_bytes)
             if rank == 0:                                 # one launch restores the row order of all B frames
@@ -562,6 +677,20 @@ def main():
         dominant = {"tree": "p3d::whitted_tree_kernel", "tile": "p3d::wf_tile_kernel", "wavefront": "p3d::wf_primary_kernel"}[chosen]
         live = {"kernel": dominant, "schedule": chosen, "kernel_ms": kern_ms, "frame_ms": frame_dev_ms, "alg_bytes": int(alg_bytes),
                 "alg_gbps": alg_bytes / (frame_dev_ms * 1e-3) / 1e9}
+        gather_verified = None
+        if world > 1:
+            # the gathered, de-interleaved frame against a one-GPU render of the same frame on this rank
+            whole = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+            kw1 = dict(kw, rank=0, world=1)
+            ds.render_device(cam, rgb8_ptr=whole.data_ptr(), **sched, **kw1)
+            ds.sync()
+            gather_verified = bool(np.array_equal(final, whole.cpu().numpy()))
+        if synthetic:
+            data = "synthetic: %d random spheres+triangles (SURVEY 8d scaling scene, seed 2024), mount_low camera" % args.prims
+        else:
+            data = ("P3D_Scenes/%s.p3f, the reference's own scene asset (%d primitives, %d light(s)); resolution / accel / depth%s "
+                    "overridden to the configuration" % (wl["scene"], hs.n_prims, hs.n_lights,
+                                                          " / spp (host libc rand() sample stream, seed 12345)" if spp else ""))
         line = {
             "metric": "Mrays/s + ms/frame @%dx%d depth%d" % (W, H, depth),
             "value": total_rays / dt_max / 1e6,
@@ -574,10 +703,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": ("synthetic: %d random spheres+triangles (SURVEY 8d scaling scene, seed 2024), mount_low camera" % args.prims)
-                    if synthetic else
-                    "P3D_Scenes/%s.p3f, the reference's own scene asset (12 primitives, 1 light); resolution / accel / depth%s "
-                    "overridden to the configuration" % (wl["scene"], " / spp (host libc rand() sample stream, seed 12345)" if spp else ""),
+            "data": data,
             "config": {"workload": ("SURVEY 8d scaling scene, %d primitives, 1920x1080 depth 4 BVH" % args.prims) if synthetic else wl["name"],
                        "frames_per_step": B, "frames_in_flight": F, "hip_graph": graphs is not None,
                        "schedule": chosen + (" (forced)" if sched else " (library default)"),
@@ -590,11 +716,53 @@ def main():
                        "row_block": ROW_BLOCK,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs: interleaved 16-row blocks + one RCCL gather to rank 0 through the C-ABI" % world,
                        "frame_checksum": int(final.astype(np.uint64).sum())},
-            "roofline": roofline_from_profiles(args.workload, live),
+            "roofline": roofline_from_profiles(args.workload, live, "synthetic_%d" % args.prims if synthetic else None),
+            "env": {"lib": os.path.relpath(P.api.LIB_PATH, REPO), "P3D": {k: v for k, v in sorted(os.environ.items()) if k.startswith("P3D_")}},
         }
+        if world > 1:
+            line["gather_verified"] = gather_verified
+        if args.workload == "config3" and world == 1:
+            # the exact shortcut of DESIGN.md 12 as a SECOND figure: triangles no ray can hit left out of the BVH
+            hc = P.DeviceScene.from_host(hs, device=local_rank, cull_never_hit=True)
+            hc.set_stream(streams[0].cuda_stream)
+            chk = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+            for _ in range(8):
+                hc.render_device(cam, rgb8_ptr=chk.data_ptr(), **kw)
+            hc.sync()
+            ms = 0.0
+            for _ in range(20):
+                hc.render_device(cam, rgb8_ptr=chk.data_ptr(), profile=True, **kw)
+                ms += hc.profile()[0]
+            line["config"]["cull_never_hit"] = {
+                "ms_per_frame_latency": ms / 20, "Mrays_per_s": rays_frame / (ms / 20) / 1e3, "schedule": hc.last_schedule(),
+                "triangles_left_out": hc.stats()["n_culled"], "frame_equals_default_build": bool(np.array_equal(chk.cpu().numpy(), final)),
+                "note": "p3d_build_opts::cull_never_hit: same image, same ray count; NOT the headline (the default build traverses every triangle, as the reference does)"}
+            hc.close()
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_synthetic(args.prims, depth) if synthetic else \
-                cpu_baseline(scene_file, wl.get("cpu_res", (W, H)), depth, spp)
+            if synthetic:
+                line["cpu_baseline"], ref_frames = cpu_baseline_synthetic(args.prims, depth)
+            else:
+                line["cpu_baseline"], ref_frames = cpu_baseline(scene_file, (W, H), wl.get("cpu_res", (W, H)), depth, spp)
+
+            def render_sample(res):
+                """A frame of the CPU leg's sample size through the same handle: (rgb8, rays)."""
+                if synthetic:
+                    cs = P.HostScene(SY.camera_p3f(cam_file, res[0], res[1]))
+                    c2, smp2 = cs.camera(), None
+                else:
+                    cs = P.HostScene(scene_file)
+                    cs.set_resolution(res[0], res[1])
+                    c2, smp2 = cs.camera(), (cs.samples(12345, spp) if spp else None)
+                r = ds.render(c2, max_depth=depth, accel=P.ACCEL_BVH, spp=spp, samples=smp2, counters=True, want_f32=False, want_hit=False, **sched)
+                return r["rgb8"], r["counters"]["rays"]
+
+            if ref_frames is not None:
+                ok, details = frame_check(ref_frames, final, int(rays_frame), render_sample)
+                line["frame_matches_reference"] = ok
+                line["frame_check"] = details
+            else:
+                line["frame_matches_reference"] = None
+                line["frame_check"] = {"note": "no CPU frame for this size of the synthetic scene"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define P3D_ABI_VERSION 3
+#define P3D_ABI_VERSION 4
 
 typedef enum p3d_status {
     P3D_OK = 0,
@@ -130,10 +130,20 @@ typedef struct p3d_render_params {
 #define P3D_FEATURE_FUZZY_REFLECTION 2u
 
 #define P3D_FLAG_COUNTERS 1u     /* accumulate p3d_counters on the device (slower kernels)  */
-/* Kernel schedules: three ways to run the same per-node code, bit-identical frames.  Default: the tile
- * schedule for scenes up to 2 MiB; for larger ones the library times every schedule on the first frames of a
- * configuration (two frames each, the first one untimed) and keeps the fastest.  At most one of the three
- * forcing flags may be set. */
+/* Kernel schedules: three ways to run the same per-node code, bit-identical frames.  Which one p3d_render() uses
+ * when none is forced (p3d_last_schedule() reports it):
+ *   - scenes whose flattened records fit 24 KiB are rendered from an LDS copy, and go BY RULE: one-sample frames
+ *     (spp == 0) the wavefront schedule, sample loops (spp > 0) the tile schedule;
+ *   - every other scene is read from HBM / L2 and the choice is MEASURED per configuration (resolution, depth, accel,
+ *     spp, rank / world, flags): the first six frames of a configuration run the wavefront, tree and tile schedules
+ *     twice each (first run untimed: code-object load, workspace allocation; a schedule whose workspace does not fit
+ *     is skipped), the fastest one stays.  During those frames p3d_render() WAITS on a HIP event for the previous
+ *     frame's timing even when p3d_outputs::memory == 1, i.e. it is not asynchronous; a frame issued while the stream
+ *     is being captured measures nothing and uses the choice already made (the tile schedule if there is none yet).
+ * A schedule whose workspace does not fit the budget falls back tile -> wavefront (in bands) -> tree.
+ * One scene handle carries ONE frame at a time per stream: its workspace and the parity words of its queues are
+ * ordered by the stream only, so a caller must not issue frames of one handle on two streams concurrently (use one
+ * handle per stream, as bench.py does).  At most one of the three forcing flags may be set. */
 #define P3D_FLAG_TILE_KERNEL 64u /* ONE launch per frame: persistent 256-thread workgroups draw 16x16-pixel tiles and
                                     run a tile's whole ray tree level by level among themselves (queues in a
                                     private workspace slot, counters in LDS, no global atomics between levels)  */
@@ -142,16 +152,14 @@ typedef struct p3d_render_params {
                                     layout): the caller uploaded the sample array once instead of per call    */
 #define P3D_FLAG_PROFILE 16u     /* bracket the frame and its dominant kernel (the level-1 /
                                     tree launch) with HIP events for p3d_get_profile()           */
-#define P3D_FLAG_NO_PACKET 8u    /* (kept for ABI compatibility: the per-lane BVH walk is the default now)           */
 #define P3D_FLAG_PACKET_WALK 256u /* wave-wide (packet) BVH walk for trees of up to 64 node pairs: node and primitive
                                     records fetched once per wave, a node visited when any lane's slab test passes.
                                     Same results as the default per-lane walk; measured slower since the leaves
                                     became typed runs (0.137 vs 0.133 ms on BASELINE config 2)                       */
 #define P3D_FLAG_NO_LDS_SCENE 4u /* read the scene from HBM/L2 even when it would fit in LDS    */
-#define P3D_FLAG_TREE_KERNEL 2u  /* one launch, per-lane post-order frame stack in LDS, instead
-                                    of the default level-by-level wavefront schedule; results are
-                                    bit-identical (also the automatic fallback when the wavefront
-                                    queues for max_depth would not fit the workspace budget)    */
+#define P3D_FLAG_TREE_KERNEL 2u  /* one launch, each lane walks its pixel's whole tree with a post-order frame
+                                    stack (LDS, or private memory for scenes read from HBM); also the last
+                                    fallback when neither the tile nor the wavefront workspace fits the budget */
 
 /* Work counters in the unit of SURVEY §8d (one ray = one closest-hit or shadow query). */
 typedef struct p3d_counters {
@@ -193,7 +201,9 @@ int         p3d_device_count(int* count);
 
 /* Replaces init_scene()'s accelerator set-up (RT/main.cpp:912-936) and BVH::Build
  * (RT/bvh.cpp:28): flattens nothing (the caller did), builds the BVH on the host, uploads
- * scene + BVH to `device`. opts may be NULL. */
+ * scene + BVH to `device`. opts may be NULL.  The uniform grid of GRID mode (Grid::Build, RT/grid.cpp:30) is
+ * built and uploaded by the first p3d_render() with accel == P3D_ACCEL_GRID -- a one-off synchronous cost of that
+ * frame; such a frame is refused (P3D_ERR_STATE) while the stream is being captured. */
 int p3d_scene_create(const p3d_scene_desc* desc, const p3d_build_opts* opts, int device,
                      p3d_scene** out);
 int p3d_scene_destroy(p3d_scene* scene);
@@ -296,6 +306,12 @@ int p3d_download(p3d_scene* scene, void* host_dst, const void* device_src, uint6
  * closest hit, after shading, after the queue append; slot 7 = hardware id). NULL turns it off
  * (default). Never changes results. tools/stamps.py turns them into a per-stage timeline. */
 int p3d_debug_set_stamps(p3d_scene* scene, void* device_buffer);
+/* Which launch of a frame writes the stamps: 1 (default) = the level-1 launch of the wavefront schedule, or the
+ * single launch of the tree schedule (slots 0 = wave start, 4 = wave end); l >= 2 = the wavefront schedule's level-l
+ * launch, ONE RECORD PER WAVE of that launch (buffer: waves x 8 uint64; at most 65536 waves are launched): slots
+ * 0 start, 1 queue read, 2 closest hit, 3 shading (incl. shadow queries), 4 queue append / pair combine of the wave's
+ * first batch, 5 wave done, 6 = number of batches it ran, 7 = hardware id. */
+int p3d_debug_set_stamp_level(p3d_scene* scene, int32_t level);
 
 /* Unit-level probe used by the parity tests: intersect n rays with one primitive each using
  * the DEVICE intersectors (Sphere/Triangle/aaBox/Plane::intercepts, RT/scene.cpp:55-283).

@@ -4,7 +4,7 @@ measured choice between its three kernel schedules (frames must be identical whi
 import numpy as np
 import pytest
 
-from conftest import scene_path
+from conftest import scene_path, assert_rgb8_equal
 from oracle import oracle_py as O
 import u_4a_2s_p3d_raytracer_template2_amd as P
 from u_4a_2s_p3d_raytracer_template2_amd import api, synthetic as S
@@ -26,8 +26,7 @@ def test_synthetic_scene_matches_oracle(tmp_path):
         assert np.array_equal(out["hit_id"], ref["hit_id"]), kw
         assert np.abs(out["rgb32f"] - ref["rgb32f"]).max() <= 1e-4, kw
         assert out["counters"]["rays"] == ref["counters"]["rays"], kw
-        d8 = np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int))
-        assert d8.max() <= 1 and (d8 != 0).mean() <= 5e-4, kw
+        assert_rgb8_equal(out["rgb8"], ref["rgb8"], str(kw))
     ds.close()
 
 

@@ -1,8 +1,9 @@
 """The multi-GPU frame through the C-ABI on the one GPU a test box has: rank/world sharding of
 p3d_render, p3d_gather / p3d_gather_all over an RCCL communicator of size 1 (both ways of forming it),
 p3d_deinterleave on rank 0.  RCCL refuses two ranks on one device, so world > 1 transfers are exercised by
-the driver's multi-GPU run; the shard -> gather-layout -> de-interleave chain for world 2/3/8 is checked
-here with the transfers replaced by the device copies a gather amounts to."""
+the driver's multi-GPU run and by the two tests here that only run where two devices are visible (image == the
+one-GPU image, byte for byte); the shard -> gather-layout -> de-interleave chain for world 2/3/8 is checked with the
+transfers replaced by the device copies a gather amounts to."""
 import numpy as np
 import pytest
 
@@ -61,6 +62,55 @@ def test_shards_in_gather_layout_deinterleave_to_the_single_gpu_frame(world):
     ds.sync()
     assert np.array_equal(frame.cpu().numpy(), ref)
     ds.close()
+
+
+needs_two = pytest.mark.skipif(P.device_count() < 2, reason="needs two GPUs (the test boxes of a round have one; "
+                                                              "the driver's multi-GPU node runs these)")
+
+
+@needs_two
+def test_gather_all_over_two_devices_equals_the_single_gpu_frame():
+    """The first real N > 1 transfer: two devices driven from one thread (p3d_comm_create_all + p3d_gather_all: grouped
+    ncclSend / ncclRecv into rank 0's buffer over xGMI), de-interleaved on rank 0 == the one-GPU frame, byte for byte --
+    and == the device-copy stand-in of the test above."""
+    hs = P.HostScene(scene_path("balls_low"))
+    hs.set_resolution(208, 150)
+    cam = hs.camera()
+    world = 2
+    scenes = [P.DeviceScene.from_host(hs, device=r) for r in range(world)]
+    ref = scenes[0].render(cam, accel=2, max_depth=3)["rgb8"]
+    comms = P.Comm.create_all(list(range(world)))
+    rows = P.local_rows(cam.res_y, 16, world)
+    tiles = [torch.zeros((rows, cam.res_x, 3), dtype=torch.uint8, device="cuda:%d" % r) for r in range(world)]
+    gathered = torch.full((world, rows, cam.res_x, 3), 7, dtype=torch.uint8, device="cuda:0")
+    frame = torch.zeros((cam.res_y, cam.res_x, 3), dtype=torch.uint8, device="cuda:0")
+    for r in range(world):
+        scenes[r].render_device(cam, rgb8_ptr=tiles[r].data_ptr(), accel=2, max_depth=3, rank=r, world=world)
+    P.gather_all(comms, scenes, [t.data_ptr() for t in tiles], gathered.data_ptr(), tiles[0].numel())
+    scenes[0].deinterleave(gathered.data_ptr(), frame.data_ptr(), cam.res_x, cam.res_y, 16, world, 3)
+    for sc in scenes:
+        sc.sync()
+    assert np.array_equal(frame.cpu().numpy(), ref)
+    stand_in = torch.zeros_like(gathered)
+    for r in range(world):
+        scenes[0].render_device(cam, rgb8_ptr=stand_in[r].data_ptr(), accel=2, max_depth=3, rank=r, world=world)
+    scenes[0].sync()
+    assert torch.equal(stand_in, gathered)
+    for c in comms:
+        c.close()
+    for sc in scenes:
+        sc.close()
+
+
+@needs_two
+def test_cli_two_gpus_writes_the_one_gpu_image(tmp_path):
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(P.api.LIB_PATH), "p3d_render")
+    a, b = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+    subprocess.check_call([exe, scene_path("mount_low"), "--res", "320", "200", "--accel", "2", "--out", a])
+    subprocess.check_call([exe, scene_path("mount_low"), "--res", "320", "200", "--accel", "2", "--gpus", "2", "--out", b])
+    assert open(a, "rb").read() == open(b, "rb").read()
 
 
 def test_cli_renders_with_gpus_1(tmp_path):

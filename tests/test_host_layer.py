@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libp3d_hip.so does not export %s" % name
     assert sorted(api.C_ABI_SYMBOLS) == declared
-    assert L.p3d_abi_version() == 3
+    assert L.p3d_abi_version() == 4
     pt_header = open(os.path.join(REPO, "include", "p3d_pathtracer.h")).read()
     pt_declared = sorted(set(re.findall(r"\b(p3d_pt_[a-z_]+)\s*\(", pt_header)))
     assert pt_declared == sorted(api.PT_C_ABI_SYMBOLS)
@@ -71,6 +71,26 @@ def test_host_grid_is_the_reference_grid(name):
     d_o, c_o = sc.refgrid_dims(with_cells=True)
     assert np.array_equal(dims, d_o)
     assert np.array_equal(counts, c_o.astype(np.uint32))
+
+
+def test_host_grid_of_an_empty_and_of_a_flat_scene():
+    """Grid::Build's cell-count formula on no primitives is (int)NaN -- undefined behaviour in the reference; the host
+    builder answers with ONE empty cell.  A scene with no extent on one axis still gets the reference's grid (every
+    bounding box is padded by EPSILON, so the volume is never zero)."""
+    mats = np.zeros((1, 12), np.float32)
+    none = np.zeros((0, 12), np.float32)
+    desc, keep = api.make_desc(np.zeros(0, np.uint32), none, np.zeros(0, np.uint32), mats, np.zeros((0, 6), np.float32), (0, 0, 0))
+    dims, counts = api.host_grid(desc)
+    assert dims.tolist() == [1, 1, 1] and counts.tolist() == [0]
+    # two coplanar triangles and a zero-thickness box in the plane z = 0.5
+    data = np.zeros((3, 12), np.float32)
+    data[0, :9] = [0, 0, 0.5, 1, 0, 0.5, 0, 1, 0.5]
+    data[1, :9] = [1, 1, 0.5, 1, 0, 0.5, 0, 1, 0.5]
+    data[2, :6] = [0.2, 0.2, 0.5, 0.4, 0.4, 0.5]
+    desc, keep = api.make_desc(np.array([1, 1, 2], np.uint32), data, np.zeros(3, np.uint32), mats, np.zeros((0, 6), np.float32), (0, 0, 0))
+    dims, counts = api.host_grid(desc)
+    assert (dims >= 1).all() and int(np.prod(dims)) == len(counts) and counts.sum() >= 3
+    assert dims[2] == 1                      # 2 * wz * s + 1 with wz = 4 EPSILON
 
 
 def test_host_triangle_normals_are_the_reference_normals():

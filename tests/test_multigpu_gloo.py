@@ -1,6 +1,7 @@
 """world_size-2 (and 3) gloo runs of the multi-GPU plumbing on CPU: the interleaved row-block
-partition, the single gather to rank 0 (multigpu.gather_to_root, the call bench.py makes) and the
-stitch.  The per-rank tiles come from the CPU oracle here (no GPU in this test); on the GPU box
+partition, the gather to rank 0 through host memory (multigpu.gather_tiles_through_host: the function
+bench.py's N > 1 path calls when RCCL is not available -- with RCCL the same bytes move by p3d_gather,
+tests/test_gpu_multigpu.py) and the stitch.  The per-rank tiles come from the CPU oracle here (no GPU in this test); on the GPU box
 the same partition is rendered by p3d_render(rank, world) and checked against the single-launch
 image in test_gpu_parity.py."""
 import os
@@ -43,21 +44,17 @@ def _worker(rank, world, port, scene_file, out_file):
     for (l0, y0, n) in MG.block_rows(H, RB, rank, world):
         part = sc.render(max_depth=4, accel=2, y0=y0, y1=y0 + n, want_f32=False, want_hit=False)
         tile[l0:l0 + n] = part["rgb8"][y0:y0 + n]
-    t = torch.from_numpy(tile)
+    # bench.py's layout: B frames per step in one [B, rows, W, 3] tile set, [world, B, rows, W, 3] on rank 0
+    t = torch.from_numpy(np.stack([tile, tile[:, ::-1].copy()]))
     gathered = torch.zeros((world,) + tuple(t.shape), dtype=torch.uint8) if rank == 0 else None
-    g = MG.gather_to_root(t, dist, rank, world, gathered)
+    g = MG.gather_tiles_through_host(t, gathered, dist, rank, world, torch)
     if rank == 0:
-        frame = MG.stitch_reference([g[r].numpy() for r in range(world)], H, RB)
+        frame = MG.stitch_reference([g[r, 0].numpy() for r in range(world)], H, RB)
         np.save(out_file, frame)
-    # the pipelined form bench.py uses: two collectives in flight, waited for one step late
-    t2 = torch.flip(t, dims=[1]).contiguous()
-    g1 = torch.zeros_like(gathered) if rank == 0 else None
-    g2 = torch.zeros_like(gathered) if rank == 0 else None
-    w1 = MG.gather_to_root(t, dist, rank, world, g1, async_op=True)
-    w2 = MG.gather_to_root(t2, dist, rank, world, g2, async_op=True)
-    w1.wait(); w2.wait()
-    if rank == 0:
-        assert torch.equal(g1, gathered) and torch.equal(g2, torch.flip(gathered, dims=[2]))
+        flipped = MG.stitch_reference([g[r, 1].numpy() for r in range(world)], H, RB)
+        assert np.array_equal(flipped, frame[:, ::-1])
+    else:
+        assert g is None
     dist.barrier()
     dist.destroy_process_group()
 

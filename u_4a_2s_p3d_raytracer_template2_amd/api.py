@@ -14,7 +14,6 @@ ACCEL_NONE, ACCEL_GRID, ACCEL_BVH = 0, 1, 2
 FLAG_COUNTERS = 1
 FLAG_TREE_KERNEL = 2
 FLAG_NO_LDS_SCENE = 4
-FLAG_NO_PACKET = 8
 FLAG_PROFILE = 16
 FLAG_WAVEFRONT = 32
 FLAG_TILE_KERNEL = 64
@@ -82,7 +81,7 @@ class SceneStats(C.Structure):
 C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_scene_create",
                  "p3d_scene_destroy", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
                  "p3d_get_counters", "p3d_get_profile", "p3d_last_schedule", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end", "p3d_deinterleave_frames",
-                 "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_set_stamps",
+                 "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_set_stamps", "p3d_debug_set_stamp_level",
                  "p3d_comm_unique_id", "p3d_comm_create", "p3d_comm_create_all", "p3d_comm_destroy", "p3d_comm_info",
                  "p3d_gather", "p3d_gather_all", "p3d_device_alloc", "p3d_device_free", "p3d_upload", "p3d_download"]
 
@@ -134,6 +133,7 @@ def lib():
     L.p3d_deinterleave.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_uint64]
     L.p3d_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    L.p3d_debug_set_stamp_level.argtypes = [C.c_void_p, C.c_int32]
     L.p3d_comm_unique_id.argtypes = [C.c_void_p]
     L.p3d_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.p3d_comm_create_all.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
@@ -360,12 +360,15 @@ class DeviceScene:
     def debug_set_stamps(self, ptr):
         _check(lib().p3d_debug_set_stamps(self.h, C.c_void_p(ptr or None)), "p3d_debug_set_stamps")
 
+    def debug_set_stamp_level(self, level):
+        _check(lib().p3d_debug_set_stamp_level(self.h, int(level)), "p3d_debug_set_stamp_level")
+
     def counters(self):
         c = Counters()
         _check(lib().p3d_get_counters(self.h, C.byref(c)), "p3d_get_counters")
         return c.as_dict()
 
-    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False):
+    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False):
         p = RenderParams()
         p.max_depth, p.accel, p.spp = int(max_depth), int(accel), int(spp)
         p.samples = samples.ctypes.data_as(C.POINTER(C.c_float)) if samples is not None else None
@@ -374,11 +377,11 @@ class DeviceScene:
         p.row_block, p.rank, p.world = int(row_block), int(rank), int(world)
         p.features = (FEATURE_SOFT_SHADOW if soft_shadow else 0) | (FEATURE_FUZZY_REFLECTION if fuzzy_reflection else 0)
         p.seed = int(seed) & 0xFFFFFFFF
-        p.flags = (FLAG_COUNTERS if counters else 0) | (FLAG_TREE_KERNEL if tree else 0) | (FLAG_NO_LDS_SCENE if no_lds else 0) | (FLAG_NO_PACKET if no_packet else 0) | (FLAG_PROFILE if profile else 0) | (FLAG_WAVEFRONT if wavefront else 0) | (FLAG_TILE_KERNEL if tile else 0) | (FLAG_DEVICE_SAMPLES if samples_ptr else 0) | (FLAG_PACKET_WALK if packet else 0)
+        p.flags = (FLAG_COUNTERS if counters else 0) | (FLAG_TREE_KERNEL if tree else 0) | (FLAG_NO_LDS_SCENE if no_lds else 0) | (FLAG_PROFILE if profile else 0) | (FLAG_WAVEFRONT if wavefront else 0) | (FLAG_TILE_KERNEL if tile else 0) | (FLAG_DEVICE_SAMPLES if samples_ptr else 0) | (FLAG_PACKET_WALK if packet else 0)
         return p
 
     def render(self, cam, max_depth=4, accel=ACCEL_BVH, spp=0, samples=None, rank=0, world=1, row_block=16,
-               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, packet=False):
+               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, packet=False):
         """Render into host numpy arrays (rows: res_y for world==1, local_rows otherwise)."""
         rows = cam.res_y if world == 1 else local_rows(cam.res_y, row_block, world)
         rgb8 = np.zeros((rows, cam.res_x, 3), np.uint8)
@@ -386,7 +389,7 @@ class DeviceScene:
         hid = np.full((rows, cam.res_x), -2, np.int32) if want_hit else None
         if samples is not None:
             samples = np.ascontiguousarray(samples, np.float32)
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, 0, packet)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, 0, packet)
         o = Outputs(rgb8.ctypes.data, f32.ctypes.data if want_f32 else None,
                     hid.ctypes.data if want_hit else None, 0)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
@@ -396,10 +399,10 @@ class DeviceScene:
         return out
 
     def render_device(self, cam, rgb8_ptr=0, rgb32f_ptr=0, hit_ptr=0, max_depth=4, accel=ACCEL_BVH, spp=0,
-                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, no_packet=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False):
+                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False):
         """Enqueue one frame into caller-owned DEVICE buffers (raw pointers); asynchronous.  samples_ptr: the
         spp > 0 sample array as a device pointer (uploaded once by the caller) instead of `samples`."""
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, no_packet, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, samples_ptr, packet)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, samples_ptr, packet)
         o = Outputs(rgb8_ptr or None, rgb32f_ptr or None, hit_ptr or None, 1)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
 

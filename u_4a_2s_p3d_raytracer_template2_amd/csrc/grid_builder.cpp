@@ -45,7 +45,7 @@ void grid_prims_from_desc(const p3d_scene_desc& d, std::vector<GridPrim>& out) {
 
 static inline double dclamp(double x, double mn, double mx) { return x < mn ? mn : (x > mx ? mx : x); }   // RT/maths.h:50-53
 
-void build_grid(const std::vector<GridPrim>& prims, GridHost& G) {       // RT/grid.cpp:30-98
+bool build_grid(const std::vector<GridPrim>& prims, GridHost& G) {       // RT/grid.cpp:30-98
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (const GridPrim& p : prims)
         for (int a = 0; a < 3; a++) {                                    // AABB::extend, RT/boundingBox.cpp:52-60
@@ -56,7 +56,18 @@ void build_grid(const std::vector<GridPrim>& prims, GridHost& G) {       // RT/g
     const double wx = mx[0] - mn[0], wy = mx[1] - mn[1], wz = mx[2] - mn[2];
     const double s = pow((int)prims.size() / (wx * wy * wz), 0.3333333);
     const float m = 2.0f;                                                // RT/rayAccelerator.h:29
-    const int nx = m * wx * s + 1, ny = m * wy * s + 1, nz = m * wz * s + 1;
+    const double fx = m * wx * s + 1, fy = m * wy * s + 1, fz = m * wz * s + 1;
+    // No primitives (the box is still inverted: widths of -inf, s = 0, NaN counts) or coordinates that are not
+    // numbers: the reference's int conversion of such a count is undefined behaviour.  Here: ONE empty cell and the
+    // box as it stands -- an inverted box is missed by every ray (grid_init), which is what an empty grid amounts to.
+    if (prims.empty() || !(fx >= 1.0 && fy >= 1.0 && fz >= 1.0) || !std::isfinite(fx) || !std::isfinite(fy) || !std::isfinite(fz)) {
+        G.n[0] = G.n[1] = G.n[2] = 1;
+        G.cell_start.assign(2, 0u);
+        G.items.clear();
+        return true;
+    }
+    if (fx * fy * fz > 2147483647.0) return false;                       // more cells than the device's 32-bit cell index
+    const int nx = (int)fx, ny = (int)fy, nz = (int)fz;
     G.n[0] = nx; G.n[1] = ny; G.n[2] = nz;
     const size_t cells = (size_t)nx * ny * nz;
     struct Range { int x0, x1, y0, y1, z0, z1; };
@@ -85,6 +96,7 @@ void build_grid(const std::vector<GridPrim>& prims, GridHost& G) {       // RT/g
             for (int iy = r.y0; iy <= r.y1; iy++)
                 for (int ix = r.x0; ix <= r.x1; ix++) G.items[fill[(size_t)ix + (size_t)nx * iy + (size_t)nx * ny * iz]++] = prims[i].ref;
     }
+    return true;
 }
 
 }  // namespace p3d

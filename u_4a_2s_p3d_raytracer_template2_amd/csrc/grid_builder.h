@@ -26,7 +26,8 @@ struct GridPrim { float lo[3], hi[3]; uint32_t ref; };
 
 // bounding boxes of a scene description in scene order, with the reference's float arithmetic
 void grid_prims_from_desc(const p3d_scene_desc& d, std::vector<GridPrim>& out);
-void build_grid(const std::vector<GridPrim>& prims, GridHost& out);
+// false: the reference's cell-count formula asks for more than 2^31 cells (nothing is built)
+bool build_grid(const std::vector<GridPrim>& prims, GridHost& out);
 
 }  // namespace p3d
 #endif

@@ -107,7 +107,7 @@ int64_t p3dh_grid_build(const p3d_scene_desc* d, int32_t* dims, uint32_t* counts
     std::vector<p3d::GridPrim> prims;
     p3d::grid_prims_from_desc(*d, prims);
     p3d::GridHost g;
-    p3d::build_grid(prims, g);
+    if (!p3d::build_grid(prims, g)) return -1;
     dims[0] = g.n[0]; dims[1] = g.n[1]; dims[2] = g.n[2];
     const size_t cells = g.cell_start.size() - 1;
     if (counts) for (size_t c = 0; c < cells && c < counts_cap; c++) counts[c] = g.cell_start[c + 1] - g.cell_start[c];

@@ -187,7 +187,7 @@ struct p3d_scene {
     int fused_resolve_shard_px = 8192;   // frames with at most this many pixels per shard resolve all levels in one launch
     bool pair_mode = true;               // the last level combines sibling rays with their parent (LaunchParams::wf_pair_in)
     uint32_t dbg_skip = 0;               // diagnostic builds only (LaunchParams::dbg_skip)
-    unsigned long long* dbg_stamps = nullptr;
+    unsigned long long* dbg_stamps = nullptr; int dbg_stamp_level = 1;
     int occupancy = 0;     // 0 = compiler default register budget, else 5 / 6 / 8 waves per SIMD
 };
 
@@ -295,7 +295,7 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     s->device = device;
     if (const char* e = getenv("P3D_FRAME_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= kLanes) s->frame_streams = v; }
     if (const char* e = getenv("P3D_RESOLVE_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 64) s->resolve_blocks_per_shard = v; }   // tuning experiments
-    if (const char* e = getenv("P3D_FUSED_RESOLVE_PX")) s->fused_resolve_shard_px = atoi(e);
+    if (const char* e = getenv("P3D_FUSED_RESOLVE_PX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 24)) s->fused_resolve_shard_px = v; }
     s->pair_mode = getenv("P3D_NO_PAIR_MODE") == nullptr;
     if (const char* e = getenv("P3D_DEBUG_SKIP")) s->dbg_skip = (uint32_t)atoi(e);      // read by -DP3D_DEBUG_SKIP builds only
     auto bail = [&](hipError_t e, const char* what) {
@@ -553,13 +553,20 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     // reference's uniform grid per lane
     // (the per-lane walk is the default everywhere: with typed leaves it is the faster one on BASELINE config 2 too,
     //  0.133 vs 0.137 ms; P3D_FLAG_PACKET_WALK asks for the wave-wide walk, which exists for trees up to 64 node pairs)
-    const bool packet = prm->accel != P3D_ACCEL_GRID && (prm->flags & P3D_FLAG_PACKET_WALK) && !(prm->flags & P3D_FLAG_NO_PACKET) &&
+    const bool packet = prm->accel != P3D_ACCEL_GRID && (prm->flags & P3D_FLAG_PACKET_WALK) &&
                         s->stats.n_nodes <= s->packet_node_limit;
     const int walk = prm->accel == P3D_ACCEL_GRID ? 2 : (packet ? 1 : 0);
     if (prm->accel == P3D_ACCEL_GRID) {
         if (s->unit_rays_only) return fail(P3D_ERR_STATE, "scene was built with cull_never_hit: GRID mode walks the reference's grid over ALL primitives; use accel BVH");
         if (!s->grid_ready) {
-            build_grid(s->grid_src, s->grid_info);
+            // built on the first GRID frame of a scene, with synchronous allocations and copies: not something a
+            // stream capture can hold.  Render one GRID frame before capturing.
+            hipStreamCaptureStatus gcap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(s->stream, &gcap);
+            if (gcap != hipStreamCaptureStatusNone)
+                return fail(P3D_ERR_STATE, "the first GRID-mode frame of a scene builds and uploads the grid: render one before capturing the stream");
+            if (!build_grid(s->grid_src, s->grid_info)) return fail(P3D_ERR_LIMIT, "the reference's grid formula asks for more than 2^31 cells");
+            std::vector<GridPrim>().swap(s->grid_src);          // (28 B per primitive: only the build needed it)
             HIP_TRY(s->grid_cells.upload(s->grid_info.cell_start));
             HIP_TRY(s->grid_items.upload(s->grid_info.items));
             s->stats.device_bytes += s->grid_cells.bytes() + s->grid_items.bytes();
@@ -603,7 +610,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     }
     P.counters = s->d_counters;
     P.dbg_skip = s->dbg_skip;
-    P.dbg_stamps = s->dbg_stamps;
+    P.dbg_stamps = s->dbg_stamps; P.dbg_stamp_level = s->dbg_stamp_level;
     P.wf_min_width = lds_scene ? 64 : 8;
 
     // distribution-ray-tracing switches (RT/main.cpp:40-45)
@@ -723,7 +730,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         (void)hipStreamIsCapturing(s->stream, &cap);
         p3d_scene::SchedulePick& pk = s->pick;
         const int32_t key[8] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world,
-                                (int32_t)((prm->flags & (P3D_FLAG_NO_LDS_SCENE | P3D_FLAG_NO_PACKET | P3D_FLAG_COUNTERS)) | (prm->features << 8))};
+                                (int32_t)((prm->flags & (P3D_FLAG_NO_LDS_SCENE | P3D_FLAG_PACKET_WALK | P3D_FLAG_COUNTERS)) | (prm->features << 8))};
         if (cap != hipStreamCaptureStatusNone) {
             // events cannot be read while the stream is being captured: use what is known, measure nothing
             if (memcmp(key, pk.key, sizeof key) == 0 && pk.step >= 2 * NS) sched = pk.best;
@@ -908,6 +915,13 @@ int p3d_get_counters(p3d_scene* s, p3d_counters* out) {
 int p3d_debug_set_stamps(p3d_scene* s, void* device_buffer) {
     if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
     s->dbg_stamps = (unsigned long long*)device_buffer;
+    return P3D_OK;
+}
+
+int p3d_debug_set_stamp_level(p3d_scene* s, int32_t level) {
+    if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
+    if (level < 1 || level > kMaxDepth) return fail(P3D_ERR_ARG, "level must be in 1..16");
+    s->dbg_stamp_level = level;
     return P3D_OK;
 }
 

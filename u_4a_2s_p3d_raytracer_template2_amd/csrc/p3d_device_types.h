@@ -146,6 +146,7 @@ struct LaunchParams {
     uint32_t features, seed;
     const uint32_t* wf_rng_in; uint32_t* wf_rng_out;
     unsigned long long* dbg_stamps;   // diagnostic: per (tile, wave) 8 x u64 timestamps, or nullptr
+    int32_t dbg_stamp_level;          // which launch of a frame writes them: <= 1 the level-1 / tree / tile launch, l >= 2 the level-l launch
     // ---- uniform grid of GRID mode (accel 1; RT/grid.cpp): cell c holds grid_items[grid_cells[c] .. grid_cells[c+1])
     // = primitive refs (kind << 30 | index, planes kind 3) in scene order; nullptr until a GRID frame is asked for
     const uint32_t* grid_cells; const uint32_t* grid_items;

@@ -277,13 +277,23 @@ __device__ __forceinline__ TravCtx wave_stack(const LaunchParams& P, uint32_t ex
 
 // diagnostic stamps (only when a stamp buffer was set with p3d_debug_set_stamps): slot k of the
 // record of (tile, wave) gets the 100 MHz real-time counter; slot 7 the hardware id registers
+__device__ __forceinline__ void stamp_record(unsigned long long* r, int k) {
+    r[k] = __builtin_amdgcn_s_memrealtime();
+    if (k == 0) r[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                       ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
+}
 __device__ __forceinline__ void stamp(const LaunchParams& P, int tile, int k) {
-    if (P.dbg_stamps && (threadIdx.x & 63) == 0) {
-        unsigned long long* r = P.dbg_stamps + ((size_t)tile * P.wg_waves + (threadIdx.x >> 6)) * 8;
-        r[k] = __builtin_amdgcn_s_memrealtime();
-        if (k == 0) r[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
-                           ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
-    }
+    if (P.dbg_stamps && P.dbg_stamp_level <= 1 && (threadIdx.x & 63) == 0)
+        stamp_record(P.dbg_stamps + ((size_t)tile * P.wg_waves + (threadIdx.x >> 6)) * 8, k);
+}
+// the same for the deeper-level kernel (p3d_debug_set_stamp_level(l), l >= 2): one record per WAVE of the launch, written
+// for the wave's first batch -- 0 start, 1 queue read, 2 closest hit, 3 shading, 4 emit / pair combine -- then 5 = the wave
+// is done and 6 = the number of batches it ran
+__device__ __forceinline__ bool stamps_on(const LaunchParams& P) {
+    return P.dbg_stamps && P.dbg_stamp_level == P.wf_level && (threadIdx.x & 63) == 0;
+}
+__device__ __forceinline__ void stamp_wave(const LaunchParams& P, uint32_t wave_id, int k, bool first = true) {
+    if (first && stamps_on(P)) stamp_record(P.dbg_stamps + (size_t)wave_id * 8, k);
 }
 
 // level 1: camera rays of one sample pass over a band of tiles
@@ -373,7 +383,10 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
         const typename View<LDS>::type sv = View<LDS>::make(P);
         const TravCtx tc = wave_stack<LDS>(P, 0);
         Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t b = wave_id; b < total; b += n_waves) {
+        uint32_t n_batches = 0;
+        for (uint32_t b = wave_id; b < total; b += n_waves, n_batches++) {
+            const bool st1 = n_batches == 0;
+            stamp_wave(P, wave_id, 0, st1);
             const int s = (int)__builtin_ctzll(__ballot(incl > b));  // the shard batch b belongs to
             const uint32_t first = __shfl(incl - nb, s);             // batches in the shards before it
             const Shard sh = shard_of(P, (uint32_t)s, par);
@@ -389,12 +402,17 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
                 if (STOCH) rng = sh.rng_in[i];
             }
             const bool live = valid && link != kPairEmpty;           // (the unused half of a sibling pair)
+            if (stamps_on(P) && st1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_wave(P, wave_id, 1); }
             const Hit h = find_closest<COUNT, WALK>(P, sv, ray, live, tc, ctr);
+            stamp_wave(P, wave_id, 2, st1);
             const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
                                                                                     ctr, rng);
+            stamp_wave(P, wave_id, 3, st1);
             if (P.wf_pair_in) combine_pair(P, sh, live, link, o);
             else emit(P, sh, P.wf_level, live, link, ior_1, o);
+            stamp_wave(P, wave_id, 4, st1);
         }
+        if (stamps_on(P) && n_batches) { stamp_wave(P, wave_id, 5); P.dbg_stamps[(size_t)wave_id * 8 + 6] = n_batches; }
         flush_counters<COUNT>(P, ctr, 0u);
         return;
     }
@@ -416,7 +434,10 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
     const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
     const uint32_t width = wave_width(sh.count_in, per_shard, (uint32_t)P.wf_min_width);
-    for (uint32_t base = (wave_id / S) * width; base < sh.count_in; base += per_shard * width) {
+    uint32_t n_batches = 0;
+    for (uint32_t base = (wave_id / S) * width; base < sh.count_in; base += per_shard * width, n_batches++) {
+        const bool st1 = n_batches == 0;
+        stamp_wave(P, wave_id, 0, st1);
         const uint32_t i = base + lane;
         const bool valid = (uint32_t)lane < width && i < sh.count_in;
         uint32_t link = 0, rng = 0; float ior_1 = 1.0f;
@@ -430,11 +451,15 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
         }
         const bool live = valid && link != kPairEmpty;
         const Hit h = find_closest<COUNT, WALK>(P, sv, ray, live, tc, ctr);
+        stamp_wave(P, wave_id, 2, st1);
         const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
                                                                                 ctr, rng);
+        stamp_wave(P, wave_id, 3, st1);
         if (P.wf_pair_in) combine_pair(P, sh, live, link, o);
         else emit(P, sh, P.wf_level, live, link, ior_1, o);
+        stamp_wave(P, wave_id, 4, st1);
     }
+    if (stamps_on(P) && n_batches) { stamp_wave(P, wave_id, 5); P.dbg_stamps[(size_t)wave_id * 8 + 6] = n_batches; }
     flush_counters<COUNT>(P, ctr, 0u);
 }
 
@@ -753,8 +778,9 @@ template <bool COUNT, bool LDS, int OCC, bool GRID = false, int PRIV = 0>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kernel(const LaunchParams P) {
     const typename View<LDS>::type sv = View<LDS>::make(P);
     const int lane = threadIdx.x & 63;
-    int x, y, row;
-    if (!tile_pixel(P, x, y, row)) return;               // no barriers below: early exit is safe
+    int x, y, row, tile;
+    if (!tile_pixel(P, x, y, row, &tile)) return;        // no barriers below: early exit is safe
+    stamp(P, tile, 0);
     uint32_t priv[PRIV > 0 ? PRIV : 1];
     uint32_t* wbase;
     const uint32_t frame_dwords = PRIV > 0 ? 0u : (uint32_t)(P.max_depth > 1 ? (P.max_depth - 1) : 1) * 12 * 64;
@@ -781,6 +807,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kern
     write_pixel(P, p, color);
     if (P.hit_id) P.hit_id[p] = hid;
     flush_counters<COUNT>(P, ctr, 1u);
+    stamp(P, tile, 4);              // (diagnostic; the wave has reconverged here: its slowest lane is done)
 }
 
 // per-column / per-row factors of the pixel-centre camera rays (one launch per resolution)

@@ -1,7 +1,8 @@
 """Image-space sharding across ranks: interleaved row blocks + one gather.
 
-Pure index math and torch.distributed plumbing shared by bench.py and the tests; the pixels
-themselves always come from the HIP path (p3d_render with rank/world) -- nothing here renders.
+Pure index math shared by bench.py and the tests, plus the host-memory gather bench.py falls back to when RCCL is
+not available; the pixels themselves always come from the HIP path (p3d_render with rank/world) and, with RCCL up,
+move by p3d_gather behind the C-ABI -- nothing here renders.
 """
 import numpy as np
 
@@ -31,14 +32,23 @@ def stitch_reference(parts, res_y, row_block):
     return out
 
 
-def gather_to_root(tile, dist, rank, world, gathered=None, async_op=False):
-    """One collective per step: every rank's compact tile buffer -> rank 0 (direct peer->root
-    transfers over xGMI, 7 links in parallel).  `tile` and `gathered` are torch
-    tensors; gathered is [world, *tile.shape] on rank 0.  async_op=True returns the collective's
-    work handle instead of waiting for it (wait() before touching `gathered` or reusing `tile`)."""
-    if world == 1:
-        return None if async_op else tile.unsqueeze(0)
-    work = dist.gather(tile, gather_list=list(gathered.unbind(0)) if rank == 0 else None, dst=0, async_op=async_op)
-    if async_op:
-        return work
-    return gathered if rank == 0 else None
+def gather_tiles_through_host(tiles, gathered, dist, rank, world, torch, stream=None):
+    """The SAFETY NET of bench.py's N > 1 path (never the product path, and the JSON line says so): when a rank
+    could not build the RCCL communicator -- or in the one-GPU rehearsal mode -- every rank's compact tile buffers
+    travel to rank 0 through host memory with torch.distributed (gloo).  `tiles` is this rank's [B, rows, W, C]
+    tensor (device or host), `gathered` rank 0's [world, B, rows, W, C] tensor (None elsewhere); the copy into a
+    device `gathered` is enqueued on `stream`.  With RCCL up, the same bytes move by p3d_gather (include/p3d_hip.h)."""
+    if tiles.is_cuda:
+        torch.cuda.synchronize()
+    src = tiles.cpu().contiguous()
+    dst = list(torch.zeros((world,) + tuple(src.shape), dtype=src.dtype).unbind(0)) if rank == 0 else None
+    dist.gather(src, gather_list=dst, dst=0)
+    if rank != 0:
+        return None
+    stacked = torch.stack(dst)
+    if gathered.is_cuda and stream is not None:
+        with torch.cuda.stream(stream):
+            gathered.copy_(stacked)
+    else:
+        gathered.copy_(stacked)
+    return gathered
