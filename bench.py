@@ -414,8 +414,21 @@ def bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, comm):
             el = time.perf_counter() - t
             line["cpu_baseline"] = {"value": w * h * n / el / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
                                     "sample": "%dx%d, %d samples per pixel, single thread: %.1f s" % (w, h, n, el)}
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     pt.close()
+
+
+_JSON_FD = None
+
+
+def emit_line(line):
+    """The one JSON line, on the process's original stdout."""
+    data = (json.dumps(line) + "\n").encode()
+    sys.stdout.flush()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
 
 
 def main():
@@ -438,6 +451,13 @@ def main():
                     help="force a kernel schedule (default: the library's measured choice)")
     ap.add_argument("--spp", type=int, default=256, help="pathtracer workload: samples (frames) per step")
     args = ap.parse_args()
+
+    # stdout carries ONE line, the JSON: anything the libraries print on the way (the host loader echoes the camera like
+    # the reference does) goes to stderr
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
 
     # the host driver only supports dmabuf IPC: without this RCCL cannot share buffers between the ranks' processes
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -763,7 +783,7 @@ def main():
             else:
                 line["frame_matches_reference"] = None
                 line["frame_check"] = {"note": "no CPU frame for this size of the synthetic scene"}
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     if world > 1:
         dist.barrier()
         gh.close()

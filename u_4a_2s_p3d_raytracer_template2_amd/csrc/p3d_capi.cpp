@@ -21,7 +21,7 @@
 namespace p3d {
 size_t tree_kernel_lds_bytes(const LaunchParams& P, bool lds);
 size_t wavefront_lds_bytes(const LaunchParams& P, bool lds);
-hipError_t launch_tree(const LaunchParams& P, bool count, bool lds, int occ, hipStream_t stream);
+hipError_t launch_tree(const LaunchParams& P, bool count, bool lds, int occ, bool shared, hipStream_t stream);
 hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, int walk, int occ, hipStream_t stream);
 hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, int walk, int occ, unsigned waves,
                                hipStream_t stream);
@@ -108,7 +108,7 @@ struct p3d_scene {
     DevBuf<QNode> qnodes;               // 32-byte node pairs: what kernels that read the scene from HBM walk
     float q_scale[3] = {1, 1, 1}, q_base[3] = {0, 0, 0};
     uint32_t blob_quads = 0;
-    uint32_t off_nodes = 0, off_leaves = 0, off_spheres = 0, off_sphere_meta = 0, off_tris = 0, off_boxes = 0, off_mats = 0;
+    uint32_t off_nodes = 0, off_leaves = 0, off_spheres = 0, off_sphere_meta = 0, off_tris = 0, off_tri_normals = 0, off_boxes = 0, off_mats = 0;
     DevBuf<PlaneRec> planes;
     DevBuf<PrimMeta> plane_meta;
     DevBuf<LightRec> lights;
@@ -189,6 +189,11 @@ struct p3d_scene {
     uint32_t dbg_skip = 0;               // diagnostic builds only (LaunchParams::dbg_skip)
     unsigned long long* dbg_stamps = nullptr; int dbg_stamp_level = 1;
     int occupancy = 0;     // 0 = compiler default register budget, else 5 / 6 / 8 waves per SIMD
+    uint32_t tri_quads = 3;    // 16-byte quads per triangle test record (3; 4 = round 2's 64-byte stride, P3D_TRI_STRIDE=64)
+    bool verbose = false;      // P3D_VERBOSE=1: launch geometry on stderr (diagnostic)
+    int primary_tiles_per_wg = 1;   // tiles a workgroup of that launch handles one after the other
+    int primary_wg_waves = 4;  // waves per workgroup of the level-1 launch of LDS scenes (wavefront schedule, whole-frame passes)
+    int share_min_idle = 16;   // work-sharing walk of scenes read from HBM: idle lanes before a steal round (0 or > 64: private walks)
 };
 
 extern "C" int p3d_internal_set_error(int code, const char* msg) { g_err = msg ? msg : ""; return code; }
@@ -278,11 +283,12 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     } else {
         build_bvh(F.build_prims, bo, nodes, refs, bs);
     }
+    if (const char* e = getenv("P3D_NODE_ORDER")) { if (!strcmp(e, "treelet")) reorder_treelets(nodes, 4); else if (!strcmp(e, "treelet8")) reorder_treelets(nodes, 8); }
     TypedLeaves TL;
     // Scenes small enough to be rendered from an LDS copy keep a record per leaf; the others name single-type leaves
     // in the reference itself (p3d_traverse.h: sv_leaf).  Upper bound of the blob with a record per leaf:
     const size_t blob_bound = nodes.size() * (sizeof(NodePair) + 2 * sizeof(LeafRec)) + 16 + F.spheres.size() * (sizeof(SphereRec) + sizeof(PrimMeta)) +
-                              F.tris.size() * sizeof(TriRec) + F.boxes.size() * sizeof(BoxRec) + F.materials.size() * sizeof(MaterialRec) + 7 * 16;
+                              F.tris.size() * sizeof(TriRec) + F.boxes.size() * sizeof(BoxRec) + F.materials.size() * sizeof(MaterialRec) + 8 * 16;
     const bool small_scene = blob_bound <= kLdsSceneLimit;
     type_leaves(nodes, refs, F, TL, !small_scene);
     if (TL.overflow) return fail(P3D_ERR_LIMIT, "too many mixed-type leaves");
@@ -297,6 +303,11 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     if (const char* e = getenv("P3D_RESOLVE_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 64) s->resolve_blocks_per_shard = v; }   // tuning experiments
     if (const char* e = getenv("P3D_FUSED_RESOLVE_PX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 24)) s->fused_resolve_shard_px = v; }
     s->pair_mode = getenv("P3D_NO_PAIR_MODE") == nullptr;
+    s->verbose = getenv("P3D_VERBOSE") != nullptr;
+    if (const char* e = getenv("P3D_TRI_STRIDE")) s->tri_quads = atoi(e) == 64 ? 4u : 3u;
+    if (const char* e = getenv("P3D_PRIMARY_TILES")) { int v = atoi(e); if (v >= 1 && v <= 8) s->primary_tiles_per_wg = v; }
+    if (const char* e = getenv("P3D_PRIMARY_WG_WAVES")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) s->primary_wg_waves = v; }
+    if (const char* e = getenv("P3D_SHARE_MIN_IDLE")) { int v = atoi(e); if (v >= 0 && v <= 65) s->share_min_idle = v; }
     if (const char* e = getenv("P3D_DEBUG_SKIP")) s->dbg_skip = (uint32_t)atoi(e);      // read by -DP3D_DEBUG_SKIP builds only
     auto bail = [&](hipError_t e, const char* what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(e);
@@ -328,7 +339,16 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
         s->off_leaves = section(TL.leaves.data(), TL.leaves.size() * sizeof(LeafRec));
         s->off_spheres = section(spheres.data(), spheres.size() * sizeof(SphereRec));
         s->off_sphere_meta = section(sphere_meta.data(), sphere_meta.size() * sizeof(PrimMeta));
-        s->off_tris = section(tris.data(), tris.size() * sizeof(TriRec));
+        {   // triangles: 48-byte test records, shading normals out of line (p3d_device_types.h: TriRec)
+            const uint32_t tq = s->tri_quads;
+            std::vector<uint32_t> test(tris.size() * 4 * tq), nrm(tris.size() * 4);
+            for (size_t i = 0; i < tris.size(); i++) {
+                memcpy(test.data() + 4 * tq * i, &tris[i], 16 * tq);
+                memcpy(nrm.data() + 4 * i, tris[i].n, 12);
+            }
+            s->off_tris = section(test.data(), test.size() * 4);
+            s->off_tri_normals = section(nrm.data(), nrm.size() * 4);
+        }
         s->off_boxes = section(boxes.data(), boxes.size() * sizeof(BoxRec));
         s->off_mats = section(mats.data(), mats.size() * sizeof(MaterialRec));
         // the f32 nodes only travel with scenes small enough to be rendered from an LDS copy of the blob
@@ -482,7 +502,29 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
     P.wf_pair_in = 0; P.wf_pair_out = (pair_mode && D == 2) ? 1 : 0;
     P.wf_nodes_grand = nullptr; P.wf_ncap_grand = 0;
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], stream));
-    HIP_TRY(launch_wf_primary(P, count, lds, walk, occ, stream));
+    {
+        // level 1 of an LDS scene: bigger workgroups (fewer to hand out, one scene copy for more waves) when the pass is
+        // the whole frame.  Only the tile geometry of THIS launch changes: a ray's shard is still its tile's number % shards,
+        // and shard_px (the caller's) already covers the larger tiles.
+        LaunchParams P1 = P;
+        const int w1 = s->primary_wg_waves;
+        if (lds && w1 != P.wg_waves && P.wf_tile_row0 == 0 && P.wf_tile_rows == P.tiles_y) {
+            P1.wg_waves = w1;
+            P1.tiles_y = (P.local_rows + 4 * w1 - 1) / (4 * w1);
+            P1.n_tiles = P1.tiles_x * P1.tiles_y;
+            P1.wf_tile_rows = P1.tiles_y;
+            const int chunks = (P1.n_tiles + P1.xcd_chunk - 1) / P1.xcd_chunk;
+            P1.grid_blocks = ((chunks + 7) / 8) * 8 * P1.xcd_chunk;
+        }
+        P1.wf_tiles_per_wg = 1;
+        if (lds && s->primary_tiles_per_wg > 1) {
+            // ... and / or several tiles per workgroup, the grid shrunk accordingly (whole multiples of 8 workgroups)
+            P1.wf_tiles_per_wg = s->primary_tiles_per_wg;
+            const int per = (P1.grid_blocks + P1.wf_tiles_per_wg - 1) / P1.wf_tiles_per_wg;
+            P1.grid_blocks = ((per + 7) / 8) * 8;
+        }
+        HIP_TRY(launch_wf_primary(P1, count, lds, walk, occ, stream));
+    }
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], stream));
     for (int l = 2; l <= D; l++) {
         P.wf_level = l;
@@ -544,7 +586,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     P.blob = s->blob.p; P.blob_quads = s->blob_quads;
     P.qnodes = s->qnodes.p; memcpy(P.q_scale, s->q_scale, sizeof P.q_scale); memcpy(P.q_base, s->q_base, sizeof P.q_base);
     P.off_nodes = s->off_nodes; P.off_leaves = s->off_leaves; P.off_spheres = s->off_spheres;
-    P.off_sphere_meta = s->off_sphere_meta; P.off_tris = s->off_tris; P.off_boxes = s->off_boxes; P.off_mats = s->off_mats;
+    P.off_sphere_meta = s->off_sphere_meta; P.off_tris = s->off_tris; P.off_tri_normals = s->off_tri_normals; P.tri_quads = s->tri_quads; P.off_boxes = s->off_boxes; P.off_mats = s->off_mats;
     P.planes = s->planes.p; P.plane_meta = s->plane_meta.p; P.lights = s->lights.p;
     // small scenes are rendered from an LDS copy shared by the 4 waves of a 256-thread workgroup
     const bool lds_scene = !(prm->flags & P3D_FLAG_NO_LDS_SCENE) && s->lds_capable;
@@ -555,7 +597,9 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     //  0.133 vs 0.137 ms; P3D_FLAG_PACKET_WALK asks for the wave-wide walk, which exists for trees up to 64 node pairs)
     const bool packet = prm->accel != P3D_ACCEL_GRID && (prm->flags & P3D_FLAG_PACKET_WALK) &&
                         s->stats.n_nodes <= s->packet_node_limit;
-    const int walk = prm->accel == P3D_ACCEL_GRID ? 2 : (packet ? 1 : 0);
+    // scenes read from HBM: the lanes of a wave share their walks (p3d_traverse.h: closest_hit_shared), unless switched off
+    const bool shared_walk = !lds_scene && prm->accel != P3D_ACCEL_GRID && !packet && s->share_min_idle > 0 && s->share_min_idle <= 64;
+    const int walk = prm->accel == P3D_ACCEL_GRID ? 2 : (packet ? 1 : (shared_walk ? 3 : 0));
     if (prm->accel == P3D_ACCEL_GRID) {
         if (s->unit_rays_only) return fail(P3D_ERR_STATE, "scene was built with cull_never_hit: GRID mode walks the reference's grid over ALL primitives; use accel BVH");
         if (!s->grid_ready) {
@@ -583,6 +627,8 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
 #define P3D_LDS_STACK_DWORDS 64u      // RefStack: 4-byte slots (WideStack: 128)
 #endif
     P.trav_stack_dwords = P.trav_stack_entries * (lds_scene ? P3D_LDS_STACK_DWORDS : kHbmStackDwordsPerEntry);
+    if (shared_walk) P.trav_stack_dwords += kShareDwords;      // the wave's share region sits behind its stack slots
+    P.share_min_idle = (uint32_t)s->share_min_idle;
     memcpy(P.bg, s->bg, sizeof P.bg);
     memcpy(P.eye, cam->eye, sizeof P.eye); memcpy(P.u, cam->u, sizeof P.u);
     memcpy(P.v, cam->v, sizeof P.v); memcpy(P.n, cam->n, sizeof P.n);
@@ -815,6 +861,9 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         PT.tw_rays_off = 0; PT.tw_nodes_off = (uint32_t)slot_rays; PT.tw_rng_off = (uint32_t)(slot_rays + slot_nodes);
         if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
+        if (s->verbose)
+            fprintf(stderr, "p3d: tile schedule: %d workgroups (occupancy query: %d on the device), %zu B LDS each, %zu B workspace slot, %d tiles\n",
+                    tile_blocks, s->tile_occ.blocks, tile_kernel_lds_bytes(PT, lds_scene), slot_bytes, PT.n_tiles);
         HIP_TRY(launch_wf_tile(PT, count, lds_scene, walk, s->occupancy, (unsigned)tile_blocks, s->stream));
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream));
     } else if (use_tree) {
@@ -822,12 +871,17 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         P.wf_tile_row0 = 0; P.wf_tile_rows = P.tiles_y;
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
         // scenes read from HBM: a register budget of 6 waves per SIMD (dragon with the flat walk loop: 1.285 ms at 5, 1.239 at 6)
-        HIP_TRY(launch_tree(P, count, lds_scene, s->occupancy ? s->occupancy : (lds_scene ? 0 : 6), s->stream));
+        HIP_TRY(launch_tree(P, count, lds_scene, s->occupancy ? s->occupancy : (lds_scene ? 0 : 6), shared_walk, s->stream));
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream));
     } else {
         // a shard owns every kShards-th tile of the band
         const size_t band_tiles = band_tile_rows * (size_t)P.tiles_x;
-        const size_t shard_px = ((band_tiles + kShards - 1) / kShards) * 64 * P.wg_waves;
+        size_t shard_px = ((band_tiles + kShards - 1) / kShards) * 64 * P.wg_waves;
+        if (lds_scene && s->primary_wg_waves > P.wg_waves) {      // level 1 may run with larger tiles (run_wavefront_pass)
+            const size_t rows1 = 4 * (size_t)s->primary_wg_waves;
+            const size_t tiles1 = (size_t)P.tiles_x * (((size_t)P.local_rows + rows1 - 1) / rows1);
+            shard_px = std::max(shard_px, ((tiles1 + kShards - 1) / kShards) * 64 * (size_t)s->primary_wg_waves);
+        }
         for (int ln = 0; ln < lanes; ln++) {
             p3d_scene::Workspace& w = s->ws[ln];
             for (int l = 2; l <= D; l++) HIP_TRY(w.rays[l].ensure((shard_px << (l - 1)) * kShards * sizeof(RayRec)));

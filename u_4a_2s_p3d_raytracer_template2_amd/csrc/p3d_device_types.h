@@ -48,9 +48,13 @@ constexpr uint32_t kRefKindShift = 30;
 constexpr uint32_t kRefIndexMask = (1u << kRefKindShift) - 1u;
 
 struct SphereRec { float cx, cy, cz, r; };                                   // 16 B
+// Host form of a triangle.  On the device the first 48 bytes -- what an intersection test reads -- are one array with a
+// 48-byte stride (LaunchParams::tri_quads = 3 quads per triangle; 4 = the 64-byte stride of round 2, kept as a comparison switch) and the shading normals another (one quad each, read once per shaded
+// hit): 25 % fewer bytes under the leaf walks of scenes read from HBM than the 64-byte record of round 2.
 struct TriRec { float p0[3]; uint32_t scene_id; float e1[3]; uint32_t material;
-                float e2[3]; uint32_t pad;                                    // 48 B: what an intersection test reads
-                float n[3]; uint32_t pad2; };                                 // +16 B: getNormal().normalize(), read when shading a hit
+                float e2[3]; uint32_t pad;                                    // 48 B: the test record
+                float n[3]; uint32_t pad2; };                                 // +16 B: getNormal().normalize()
+
 struct BoxRec { float mn[3]; uint32_t scene_id; float mx[3]; uint32_t material; };   // 32 B
 struct PlaneRec { float nx, ny, nz, d; };                                    // 16 B
 struct PrimMeta { uint32_t scene_id, material; };   // spheres and planes keep ids out of line
@@ -77,6 +81,7 @@ struct DeviceCounters {
 };
 
 constexpr uint32_t kFeatSoftJitter = 1u, kFeatFuzzy = 2u;                  // LaunchParams::features
+constexpr uint32_t kShareDwords = 384;      // per-wave LDS of the work-sharing walk (p3d_traverse.h), behind the wave's stack slots
 
 // Everything a render launch needs, passed by value (lands in SGPRs / kernarg segment).
 struct LaunchParams {
@@ -87,13 +92,15 @@ struct LaunchParams {
     uint32_t           blob_quads;
     const QNode*       qnodes;            // quantised node pairs: what kernels that read the scene from HBM walk
     float              q_scale[3], q_base[3];
-    uint32_t           off_nodes, off_leaves, off_spheres, off_sphere_meta, off_tris, off_boxes, off_mats;
+    uint32_t           off_nodes, off_leaves, off_spheres, off_sphere_meta, off_tris, off_tri_normals, off_boxes, off_mats;
+    uint32_t           tri_quads;         // quads between two triangles' test records: 3 (48-byte records, normals out of line) or 4
     int32_t            wg_waves;          // waves per workgroup of this launch (1, or 4 with an LDS scene)
     const PlaneRec*    planes;
     const PrimMeta*    plane_meta;
     const LightRec*    lights;
     uint32_t n_planes, n_lights, n_materials;
-    uint32_t trav_stack_entries, trav_stack_dwords;   // walk-stack slots per lane; dwords of a wave's stack region
+    uint32_t trav_stack_entries, trav_stack_dwords;   // walk-stack slots per lane; dwords of a wave's stack region (incl. the share region)
+    uint32_t share_min_idle;          // work-sharing walk (p3d_traverse.h): idle lanes a wave must have before they take over pending subtrees
     float bg[3];
     // camera (RT/camera.h)
     float eye[3], u[3], v[3], n[3];
@@ -115,6 +122,7 @@ struct LaunchParams {
     int32_t wf_level;              // tree level this launch traces / resolves (1 = primary rays)
     int32_t wf_sample, wf_nsamples;
     int32_t wf_tile_row0, wf_tile_rows;      // band of 16x4-tile rows handled by this pass
+    int32_t wf_tiles_per_wg;                 // level-1 launch: tiles a workgroup handles one after the other (>= 1)
     // The queues are split into wf_shards independent shards (tile t -> shard t % wf_shards; a
     // ray stays in its pixel's shard for its whole tree) so that the per-wave slot allocation
     // atomics spread over wf_shards counters instead of serialising on one word.  Pointers below

@@ -88,13 +88,13 @@ __global__ __launch_bounds__(256) void sum_samples_kernel(const LaunchParams P, 
 }
 
 // tile -> pixel.  Returns false for lanes outside the image.
-__device__ __forceinline__ bool tile_pixel(const LaunchParams& P, int& x, int& y, int& row, int* tile_out = nullptr) {
+__device__ __forceinline__ bool tile_pixel(const LaunchParams& P, int& x, int& y, int& row, int* tile_out = nullptr, int vbid = -1) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // XCD-aware tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
     // share one, each XCD has its own L2), so XCD k is given CHUNKS of xcd_chunk consecutive
     // tiles: chunk c goes to XCD c % 8.  xcd_chunk = 1 is the identity map (best load balance),
     // larger chunks trade balance for L2 locality on scenes whose BVH does not fit one L2.
-    const int bid = blockIdx.x;
+    const int bid = vbid >= 0 ? vbid : (int)blockIdx.x;      // (vbid: a workgroup that handles several tiles numbers them itself)
     const int j = bid >> 3;
     const int tile = ((j / P.xcd_chunk) * 8 + (bid & 7)) * P.xcd_chunk + (j % P.xcd_chunk);
     x = 0; y = 0; row = 0;
@@ -218,7 +218,7 @@ template <> struct View<false> {
     typedef GlobalScene type;
     static __device__ __forceinline__ GlobalScene make(const LaunchParams& P) {
         GlobalScene g; g.q = reinterpret_cast<const float4*>(P.blob);
-        g.o = SceneOffsets{P.off_nodes, P.off_leaves, P.off_spheres, P.off_sphere_meta, P.off_tris, P.off_boxes, P.off_mats};
+        g.o = SceneOffsets{P.off_nodes, P.off_leaves, P.off_spheres, P.off_sphere_meta, P.off_tris, P.off_tri_normals, P.off_boxes, P.off_mats, P.tri_quads};
         g.qn = reinterpret_cast<const uint4*>(P.qnodes);
         for (int a = 0; a < 3; a++) { g.qs[a] = P.q_scale[a]; g.qb[a] = P.q_base[a]; }
         return g;
@@ -233,7 +233,7 @@ template <> struct View<true> {
         for (uint32_t i = threadIdx.x; i < P.blob_quads; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
         LdsScene l;
-        l.o = SceneOffsets{P.off_nodes, P.off_leaves, P.off_spheres, P.off_sphere_meta, P.off_tris, P.off_boxes, P.off_mats};
+        l.o = SceneOffsets{P.off_nodes, P.off_leaves, P.off_spheres, P.off_sphere_meta, P.off_tris, P.off_tri_normals, P.off_boxes, P.off_mats, P.tri_quads};
         return l;
     }
     static __device__ __forceinline__ uint32_t scene_dwords(const LaunchParams& P) { return P.blob_quads * 4; }
@@ -272,6 +272,7 @@ __device__ __forceinline__ TravCtx wave_stack(const LaunchParams& P, uint32_t ex
     TravCtx tc;
     tc.lane.region = base; tc.lane.lane = threadIdx.x & 63; tc.lane.slots = P.trav_stack_entries;
     tc.wave.base = reinterpret_cast<int32_t*>(base);     // the two walks never run in the same launch
+    tc.share = base + P.trav_stack_dwords - kShareDwords; // work-sharing walk: the last kShareDwords of the wave's region (host: p3d_render)
     return tc;
 }
 
@@ -309,8 +310,11 @@ __device__ __forceinline__ void stamp_wave(const LaunchParams& P, uint32_t wave_
 // grid, scene copied once per workgroup, every wave drawing 16x4 tiles from device counters with the next number
 // prefetched -- was measured and dropped: 520 us with one counter (a word saturates at ~88 returning atomics per
 // microsecond), 110 us with 64 counters on separate lines, against 50 us for this plain grid.)
+// (LDS scenes: up to 16 waves per workgroup -- LaunchParams::wg_waves of THIS launch -- because workgroups are handed
+//  out at ~200 per microsecond whatever their size (profiles/r03_timelines.txt: 8160 four-wave workgroups of config 2 take
+//  40 of the launch's 46 us to start, with half the wave slots empty), and a bigger workgroup shares one scene copy)
 template <bool COUNT, bool LDS, int WALK, int OCC, bool STOCH = false>
-__global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel(const LaunchParams P) {
+__global__ __launch_bounds__(LDS ? 1024 : 64) P3D_OCC(OCC) void wf_primary_kernel(const LaunchParams P) {
     const uint32_t par = P.wf_ctrl[0] & 1u;                     // this pass's counter set (LaunchParams::wf_alt)
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) P.wf_ctrl[32] = par;
@@ -319,28 +323,35 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel
         for (uint32_t i = threadIdx.x; i < 2u * (uint32_t)P.wf_shards; i += blockDim.x) other[i] = 0u;
     }
     const typename View<LDS>::type sv = View<LDS>::make(P);
-    int x, y, row, tile;
-    const bool valid = tile_pixel(P, x, y, row, &tile);
-    if (__ballot(valid) == 0) return;
-    const Shard sh = shard_of(P, (uint32_t)tile % (uint32_t)P.wf_shards, par);
     const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
-    const size_t p = (size_t)row * P.res_x + x;
-    stamp(P, tile, 0);
-    Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
-    if (valid) ray = camera_ray(P, x, y, P.wf_sample);
-    stamp(P, tile, 1);
-    const Hit h = find_closest<COUNT, WALK>(P, sv, ray, valid, tc, ctr);
-    stamp(P, tile, 2);
-    if (valid && P.hit_id && P.wf_sample == 0) P.hit_id[p] = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid;
-    // the random stream of a pixel sample is keyed by the pixel's place in the FULL frame, so a frame
-    // sharded over several GPUs draws the same numbers as on one
-    const uint32_t rng = STOCH ? rng_mix(rng_mix(P.seed, (uint32_t)(y * P.res_x + x)), (uint32_t)P.wf_sample) : 0u;
-    const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr, rng);
-    stamp(P, tile, 3);
-    emit(P, sh, 1, valid, (uint32_t)p, 1.0f, o);
-    stamp(P, tile, 4);
-    if (valid) flush_counters<COUNT>(P, ctr, P.wf_sample == 0 ? 1u : 0u);
+    uint32_t my_pixels = 0;
+    // wf_tiles_per_wg tiles per workgroup, one after the other (tile k of workgroup b = b + k * gridDim.x: far apart in the
+    // image, so the cheap and the expensive ones mix): a wave's fixed costs -- being launched, the scene copy, the
+    // launch parameters -- are paid once for all of them
+    for (int it = 0; it < P.wf_tiles_per_wg; it++) {
+        int x, y, row, tile;
+        const bool valid = tile_pixel(P, x, y, row, &tile, (int)(blockIdx.x + (uint32_t)it * gridDim.x));
+        if (__ballot(valid) == 0) continue;
+        const Shard sh = shard_of(P, (uint32_t)tile % (uint32_t)P.wf_shards, par);
+        const size_t p = (size_t)row * P.res_x + x;
+        stamp(P, tile, 0);
+        Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
+        if (valid) ray = camera_ray(P, x, y, P.wf_sample);
+        stamp(P, tile, 1);
+        const Hit h = find_closest<COUNT, WALK>(P, sv, ray, valid, tc, ctr);
+        stamp(P, tile, 2);
+        if (valid && P.hit_id && P.wf_sample == 0) P.hit_id[p] = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid;
+        // the random stream of a pixel sample is keyed by the pixel's place in the FULL frame, so a frame
+        // sharded over several GPUs draws the same numbers as on one
+        const uint32_t rng = STOCH ? rng_mix(rng_mix(P.seed, (uint32_t)(y * P.res_x + x)), (uint32_t)P.wf_sample) : 0u;
+        const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr, rng);
+        stamp(P, tile, 3);
+        emit(P, sh, 1, valid, (uint32_t)p, 1.0f, o);
+        stamp(P, tile, 4);
+        my_pixels += (valid && P.wf_sample == 0) ? 1u : 0u;
+    }
+    if (COUNT) flush_counters<COUNT>(P, ctr, my_pixels);
 }
 
 // Lanes a wave of a deeper level uses: a short queue is spread over ALL the shard's waves with
@@ -611,11 +622,18 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
     const int D = P.max_depth, ns = P.spp > 0 ? P.spp * P.spp : 1;
     uint32_t my_pixels = 0;
+    int prev_tile = -1;
     for (;;) {
         if (tid == 0) T->tile = atomicAdd(&P.tw_ctrl[0], 1u);
         __syncthreads();
         const int tile = (int)T->tile;
         if (tile >= P.n_tiles) break;                            // workgroup-uniform
+        if (P.dbg_stamps && tid == 0) {                          // diagnostic: one record per TILE (0 start, 1 end, 2 workgroup)
+            if (prev_tile >= 0) P.dbg_stamps[(size_t)prev_tile * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+            P.dbg_stamps[(size_t)tile * 8] = __builtin_amdgcn_s_memrealtime();
+            P.dbg_stamps[(size_t)tile * 8 + 2] = blockIdx.x;
+        }
+        prev_tile = tile;
         X.tx = tile % P.tiles_x; X.ty = tile / P.tiles_x;
         const int x = X.tx * 16 + (lane & 15);
         const int row = X.ty * 16 + wave * 4 + (lane >> 4);      // row in the compact local buffer
@@ -677,6 +695,7 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
         }
         my_pixels += inside ? 1u : 0u;
     }
+    if (P.dbg_stamps && tid == 0 && prev_tile >= 0) P.dbg_stamps[(size_t)prev_tile * 8 + 1] = __builtin_amdgcn_s_memrealtime();
     flush_counters<COUNT>(P, ctr, my_pixels);
     // the last workgroup out re-arms the tile counter for the next launch on this workspace (the frame
     // is self-contained on the device: safe to capture into a HIP graph and replay)
@@ -773,13 +792,87 @@ __device__ __forceinline__ V3 trace_tree(const LaunchParams& P, const SV& sv, Ra
     }
 }
 
+// The same trees with the wave's lanes in ONE loop (work-sharing walk, WALK_SHARED): every iteration all 64 lanes reach
+// find_closest() / shade_hit() together -- a lane whose pixel is finished (or outside the image) comes along as a helper
+// of the others' walks -- and a lane that finishes a sample's tree starts its next sample at once.
+template <bool COUNT, class SV, class FR>
+__device__ __forceinline__ void trace_trees_shared(const LaunchParams& P, const SV& sv, int x, int y, bool valid, const TravCtx& tc, FR fr,
+                                                   V3& color, int32_t& hid, Ctr& ctr) {
+    const int ns = P.spp > 0 ? P.spp * P.spp : 1;
+    const V3 zero = mk(0.0f, 0.0f, 0.0f);
+    int smp = 0, fsp = 0;
+    float ior_1 = 1.0f;
+    bool alive = valid, first = true;
+    V3 acc = zero;
+    Ray ray; ray.o = zero; ray.d = mk(1.0f, 0.0f, 0.0f);
+    if (alive) ray = camera_ray(P, x, y, 0);
+    while (__ballot(alive) != 0) {
+        const Hit h = find_closest<COUNT, WALK_SHARED>(P, sv, ray, alive, tc, ctr);
+        if (alive && first) { if (smp == 0) hid = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid; first = false; }
+        const NodeOut o = shade_hit<COUNT, WALK_SHARED>(P, sv, ray, h, alive, fsp + 1, ior_1, tc, ctr);
+        if (!alive) continue;
+        if (!o.terminal) {
+            fr.put3(fsp, FR_C, o.color);
+            fr.f(fsp, FR_KR) = __float_as_uint(o.KR);
+            if (o.has_refl) {
+                fr.f(fsp, FR_META) = o.mat | (o.has_refr ? FR_HAS_REFR : 0u);
+                fr.put3(fsp, FR_A, o.refr.o);
+                fr.put3(fsp, FR_RD, o.refr.d);
+                fr.f(fsp, FR_IOR) = __float_as_uint(o.newIor);
+                ray = o.refl;                                    // ior_1 unchanged
+            } else {
+                Mtl M = load_material(sv, o.mat);
+                fr.f(fsp, FR_META) = o.mat | FR_WAIT_REFR;
+                fr.put3(fsp, FR_A, cmul(mul(zero, o.KR), M.spec));
+                ray = o.refr; ior_1 = o.newIor;
+            }
+            fsp++;
+            continue;
+        }
+        V3 ret = o.ret;
+        bool resumed = false;                                    // ---- return path: combine into parents (RT/main.cpp:719)
+        while (fsp > 0) {
+            const int k = fsp - 1;
+            const uint32_t meta = fr.f(k, FR_META);
+            const V3 C = fr.get3(k, FR_C);
+            const float KR = __uint_as_float(fr.f(k, FR_KR));
+            if (!(meta & FR_WAIT_REFR)) {
+                Mtl M = load_material(sv, meta & 0x3FFFFFFFu);
+                const V3 A = cmul(mul(ret, KR), M.spec);
+                if (meta & FR_HAS_REFR) {
+                    ray.o = fr.get3(k, FR_A);
+                    ray.d = fr.get3(k, FR_RD);
+                    ior_1 = __uint_as_float(fr.f(k, FR_IOR));
+                    fr.put3(k, FR_A, A);
+                    fr.f(k, FR_META) = meta | FR_WAIT_REFR;
+                    resumed = true;
+                    break;
+                }
+                ret = add(C, add(A, mul(zero, 1.0f - KR)));
+            } else {
+                const V3 A = fr.get3(k, FR_A);
+                ret = add(C, add(A, mul(ret, 1.0f - KR)));
+            }
+            fsp--;
+        }
+        if (resumed) continue;
+        const V3 c = clampc(ret);                                // "rayTracing(...).clamp()" of this sample
+        if (P.spp == 0) { color = c; alive = false; continue; }
+        acc = add(acc, c);                                       // RT/main.cpp:797, in sample order
+        smp++;
+        if (smp < ns) { ray = camera_ray(P, x, y, smp); fsp = 0; ior_1 = 1.0f; }
+        else { color = mk(fdiv(acc.x, 16.0f), fdiv(acc.y, 16.0f), fdiv(acc.z, 16.0f)); alive = false; }
+    }
+}
+
 // PRIV = dwords of private memory for the frames (12 per level below the first), 0 = frames in LDS
-template <bool COUNT, bool LDS, int OCC, bool GRID = false, int PRIV = 0>
+template <bool COUNT, bool LDS, int OCC, bool GRID = false, int PRIV = 0, bool SHARED = false>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kernel(const LaunchParams P) {
     const typename View<LDS>::type sv = View<LDS>::make(P);
     const int lane = threadIdx.x & 63;
     int x, y, row, tile;
-    if (!tile_pixel(P, x, y, row, &tile)) return;        // no barriers below: early exit is safe
+    const bool in_image = tile_pixel(P, x, y, row, &tile);
+    if (SHARED ? __ballot(in_image) == 0 : !in_image) return;   // no barriers below: early exit is safe
     stamp(P, tile, 0);
     uint32_t priv[PRIV > 0 ? PRIV : 1];
     uint32_t* wbase;
@@ -791,6 +884,17 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kern
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
     V3 color = mk(0.0f, 0.0f, 0.0f);
     int32_t hid = -1;
+    if constexpr (SHARED) {
+        trace_trees_shared<COUNT>(P, sv, x, y, in_image, st, fr, color, hid, ctr);
+        if (in_image) {
+            const size_t p = (size_t)row * P.res_x + x;
+            write_pixel(P, p, color);
+            if (P.hit_id) P.hit_id[p] = hid;
+            flush_counters<COUNT>(P, ctr, 1u);
+        }
+        stamp(P, tile, 4);
+        return;
+    }
     if (P.spp == 0) {                                    // RT/main.cpp:756-775
         color = clampc(trace_tree<COUNT, GRID>(P, sv, camera_ray(P, x, y, 0), st, fr, hid, ctr));
     } else {                                             // RT/main.cpp:776-801
@@ -908,6 +1012,12 @@ template <class F> static const void* fn_ptr(F f) { return reinterpret_cast<cons
 #define P3D_DEFINE_SELECTOR(NAME, KERNEL)                                                                         \
     static const void* NAME(bool count, bool lds, int walk, int occ, bool stoch) {                                \
         if (walk == WALK_GRID || count || stoch) occ = 1;                                                         \
+        if (walk == WALK_SHARED && !lds) {                                                                        \
+            if (stoch) return count ? fn_ptr(KERNEL<true, false, 3, 1, true>) : fn_ptr(KERNEL<false, false, 3, 1, true>);                                                                  \
+            if (count) return fn_ptr(KERNEL<true, false, 3, 1, false>);                                           \
+            return occ == 5 ? fn_ptr(KERNEL<false, false, 3, 5, false>) : occ == 6 ? fn_ptr(KERNEL<false, false, 3, 6, false>) : fn_ptr(KERNEL<false, false, 3, 1, false>);               \
+        }                                                                                                         \
+        if (walk == WALK_SHARED) walk = WALK_LANE;                                                                \
         if (stoch) {                                                                                              \
             if (count) return lds ? (walk == 2 ? fn_ptr(KERNEL<true, true, 2, 1, true>) : walk == 1 ? fn_ptr(KERNEL<true, true, 1, 1, true>) : fn_ptr(KERNEL<true, true, 0, 1, true>))       \
                                   : (walk == 2 ? fn_ptr(KERNEL<true, false, 2, 1, true>) : walk == 1 ? fn_ptr(KERNEL<true, false, 1, 1, true>) : fn_ptr(KERNEL<true, false, 0, 1, true>));   \
@@ -929,7 +1039,21 @@ P3D_DEFINE_SELECTOR(wf_secondary_fn, wf_secondary_kernel)
 P3D_DEFINE_SELECTOR(wf_tile_fn, wf_tile_kernel)
 #undef P3D_DEFINE_SELECTOR
 
-static const void* tree_fn(bool count, bool lds, int occ, bool grid, int priv = 0) {
+static const void* tree_fn(bool count, bool lds, int occ, bool grid, int priv = 0, bool shared = false) {
+    if (shared && !lds && !grid && priv == 36) {
+        if (count) return fn_ptr(whitted_tree_kernel<true, false, 1, false, 36, true>);
+        return occ == 5 ? fn_ptr(whitted_tree_kernel<false, false, 5, false, 36, true>) : occ == 6 ? fn_ptr(whitted_tree_kernel<false, false, 6, false, 36, true>)
+                                                                                                 : fn_ptr(whitted_tree_kernel<false, false, 1, false, 36, true>);
+    }
+    if (shared && !lds && !grid && priv == 84) {
+        if (count) return fn_ptr(whitted_tree_kernel<true, false, 1, false, 84, true>);
+        return occ == 5 ? fn_ptr(whitted_tree_kernel<false, false, 5, false, 84, true>) : occ == 6 ? fn_ptr(whitted_tree_kernel<false, false, 6, false, 84, true>)
+                                                                                                 : fn_ptr(whitted_tree_kernel<false, false, 1, false, 84, true>);
+    }
+    if (shared && !lds && !grid && priv == 0) {
+        if (count) return fn_ptr(whitted_tree_kernel<true, false, 1, false, 0, true>);
+        return fn_ptr(whitted_tree_kernel<false, false, 1, false, 0, true>);
+    }
     if (grid) return count ? (lds ? fn_ptr(whitted_tree_kernel<true, true, 1, true>) : fn_ptr(whitted_tree_kernel<true, false, 1, true>))
                            : (lds ? fn_ptr(whitted_tree_kernel<false, true, 1, true>) : fn_ptr(whitted_tree_kernel<false, false, 1, true>));
     if (!lds && priv == 36) {
@@ -953,8 +1077,8 @@ static hipError_t launch_by_pointer(const void* fn, const LaunchParams& P, dim3 
     return hipLaunchKernel(fn, grid, block, args, shmem, stream);
 }
 
-hipError_t launch_tree(const LaunchParams& P, bool count, bool lds, int occ, hipStream_t stream) {
-    return launch_by_pointer(tree_fn(count, lds, occ, P.accel == 1, tree_private_dwords(P, lds)), P, dim3((unsigned)P.grid_blocks),
+hipError_t launch_tree(const LaunchParams& P, bool count, bool lds, int occ, bool shared, hipStream_t stream) {
+    return launch_by_pointer(tree_fn(count, lds, occ, P.accel == 1, tree_private_dwords(P, lds), shared), P, dim3((unsigned)P.grid_blocks),
                              dim3(64 * P.wg_waves), tree_kernel_lds_bytes(P, lds), stream);
 }
 hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, int walk, int occ, hipStream_t stream) {
@@ -1029,7 +1153,8 @@ hipError_t launch_sum_samples(const LaunchParams& P, size_t first_px, size_t n_p
 hipError_t prepare_kernels(size_t max_lds) {
     // only the tree kernel without an LDS scene copy can need more than the 64 KiB default
     const void* fns[] = {tree_fn(true, false, 1, false), tree_fn(false, false, 1, false), tree_fn(false, false, 5, false),
-                         tree_fn(false, false, 6, false), tree_fn(true, false, 1, true), tree_fn(false, false, 1, true)};
+                         tree_fn(false, false, 6, false), tree_fn(true, false, 1, true), tree_fn(false, false, 1, true),
+                         tree_fn(true, false, 1, false, 0, true), tree_fn(false, false, 1, false, 0, true)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
         if (e != hipSuccess) return e;

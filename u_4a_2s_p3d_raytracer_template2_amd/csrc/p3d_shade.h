@@ -47,13 +47,35 @@ __device__ __forceinline__ Mtl load_material(const SV& sv, uint32_t m) {
 // Traversal context of a lane: its private stack (per-lane walk) and its wave's shared stack
 // (packet walk).  WALK selects the walk at compile time: 0 = per-lane BVH walk, 1 = wave-wide (packet) BVH
 // walk -- identical results -- and 2 = the reference's uniform grid (GRID mode, accel 1: its own semantics).
-struct TravCtx { TravStack lane; WaveStack wave; };
-enum { WALK_LANE = 0, WALK_PACKET = 1, WALK_GRID = 2 };
+struct TravCtx { TravStack lane; WaveStack wave; uint32_t* share; };
+// WALK_SHARED (scenes read from HBM only): the per-lane walk with the lanes of a wave sharing their pending subtrees
+// (p3d_traverse.h: closest_hit_shared).  Like the packet walk it must be reached by all lanes of the wave together.
+enum { WALK_LANE = 0, WALK_PACKET = 1, WALK_GRID = 2, WALK_SHARED = 3 };
+
+template <bool COUNT> __device__ __forceinline__ Hit closest_shared(const LaunchParams& P, const GlobalScene& sv, const Ray& ray, bool active,
+                                                                    const TravCtx& tc, Ctr& ctr) {
+    return closest_hit_shared<COUNT>(P, sv, ray, active, tc.lane, tc.share, ctr);
+}
+template <bool COUNT> __device__ __forceinline__ Hit closest_shared(const LaunchParams& P, const LdsScene& sv, const Ray& ray, bool active,
+                                                                    const TravCtx& tc, Ctr& ctr) {      // (never selected: LDS scenes keep the private walk)
+    Hit h; h.t = 3.402823466e+38f; h.ref = 0xFFFFFFFFu; h.sid = 0xFFFFFFFFu; h.mat = 0;
+    if (active) h = closest_hit<COUNT>(P, sv, ray, tc.lane, ctr);
+    return h;
+}
+template <bool COUNT> __device__ __forceinline__ bool any_shared(const LaunchParams& P, const GlobalScene& sv, const Ray& sr, bool need, bool bounded,
+                                                                 float length, const TravCtx& tc, Ctr& ctr) {
+    return any_hit_shared<COUNT>(P, sv, sr, need, bounded, length, tc.lane, tc.share, ctr);
+}
+template <bool COUNT> __device__ __forceinline__ bool any_shared(const LaunchParams& P, const LdsScene& sv, const Ray& sr, bool need, bool bounded,
+                                                                 float length, const TravCtx& tc, Ctr& ctr) {
+    return need ? any_hit<COUNT>(P, sv, sr, bounded, length, tc.lane, ctr) : false;
+}
 
 template <bool COUNT, int WALK, class SV>
 __device__ __forceinline__ Hit find_closest(const LaunchParams& P, const SV& sv, const Ray& ray, bool active,
                                             const TravCtx& tc, Ctr& ctr) {
     if (WALK == WALK_PACKET) return closest_hit_packet<COUNT>(P, sv, ray, active, tc.wave, ctr);
+    if (WALK == WALK_SHARED) return closest_shared<COUNT>(P, sv, ray, active, tc, ctr);
     Hit h; h.t = 3.402823466e+38f; h.ref = 0xFFFFFFFFu; h.sid = 0xFFFFFFFFu; h.mat = 0;
     if (active) h = (WALK == WALK_GRID) ? grid_closest<COUNT>(P, sv, ray, ctr) : closest_hit<COUNT>(P, sv, ray, tc.lane, ctr);
     return h;
@@ -70,6 +92,7 @@ __device__ __forceinline__ bool light_occluded(const LaunchParams& P, const SV& 
     const bool bounded = WALK == WALK_GRID || P.accel != 0;
     if (bounded && need) { length = vlen(sr.d); sr.d = normalized(sr.d); }
     if (WALK == WALK_PACKET) return any_hit_packet<COUNT>(P, sv, sr, need, bounded, length, tc.wave, ctr);
+    if (WALK == WALK_SHARED) return any_shared<COUNT>(P, sv, sr, need, bounded, length, tc, ctr);
     if (WALK == WALK_GRID) return need ? grid_any<COUNT>(P, sv, sr, length, ctr) : false;   // Grid::Traverse(Ray&), RT/grid.cpp:313
     return need ? any_hit<COUNT>(P, sv, sr, bounded, length, tc.lane, ctr) : false;
 }

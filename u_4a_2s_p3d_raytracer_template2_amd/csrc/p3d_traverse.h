@@ -30,7 +30,7 @@ struct Hit {
 // clock of the vector L1 return path and same-address lanes broadcast).
 extern __shared__ __attribute__((aligned(16))) uint32_t p3d_lds[];
 
-struct SceneOffsets { uint32_t nodes, leaves, spheres, sphere_meta, tris, boxes, mats; };
+struct SceneOffsets { uint32_t nodes, leaves, spheres, sphere_meta, tris, tri_normals, boxes, mats, tri_quads; };
 
 struct GlobalScene {
     const float4* q; SceneOffsets o;
@@ -79,9 +79,9 @@ template <class SV> __device__ __forceinline__ PrimMeta sv_sphere_meta(const SV&
     uint2 m = sv.ld2(sv.o.sphere_meta, i); PrimMeta r; r.scene_id = m.x; r.material = m.y; return r;
 }
 template <class SV> __device__ __forceinline__ void sv_tri(const SV& sv, uint32_t i, float4& a, float4& b, float4& c) {
-    uint32_t q = sv.o.tris + i * 4u; a = sv.ld4(q); b = sv.ld4(q + 1); c = sv.ld4(q + 2);
+    uint32_t q = sv.o.tris + i * sv.o.tri_quads; a = sv.ld4(q); b = sv.ld4(q + 1); c = sv.ld4(q + 2);
 }
-template <class SV> __device__ __forceinline__ float4 sv_tri_normal(const SV& sv, uint32_t i) { return sv.ld4(sv.o.tris + i * 4u + 3u); }
+template <class SV> __device__ __forceinline__ float4 sv_tri_normal(const SV& sv, uint32_t i) { return sv.ld4(sv.o.tri_normals + i); }
 template <class SV> __device__ __forceinline__ void sv_box(const SV& sv, uint32_t i, float4& a, float4& b) {
     uint32_t q = sv.o.boxes + i * 2u; a = sv.ld4(q); b = sv.ld4(q + 1);
 }
@@ -465,6 +465,246 @@ __device__ __forceinline__ bool any_hit(const LaunchParams& P, const SV& sv, con
         }
     }
     return false;
+}
+
+
+// ------------------------------------------------------------------ work-sharing per-lane walk (scenes read from HBM)
+// What the per-wave timelines of round 3 showed (profiles/r03_timelines.txt): on scenes read from HBM a launch lasts as
+// long as its slowest WAVES, and a wave as long as its slowest LANE -- on the dragon (100 000 triangles the reference's
+// epsilon makes invisible, SURVEY Q7: a ray through them never finds the hit that would end its walk) single waves live
+// 1 ms of a 1.3 ms launch with a handful of lanes walking and 50-60 idle, while the chip runs a third full.
+// So the lanes of a wave SHARE their walks.  All 64 lanes stay in one wave-uniform loop; a lane that has finished (or
+// never had a ray) is idle.  When enough lanes are idle and some lane has pending subtrees on its stack, each idle lane
+// takes the BOTTOM entry (the subtree nearest the root: the biggest piece of pending work) of one such lane's stack,
+// together with that lane's ray (ds_bpermute), and walks it with its own stack as a helper of that ray's OWNER.  Results
+// are merged through the wave's LDS: closest hit = minimum over (t, scene id) of everything any lane found for the owner
+// (64-bit ds_min: the reference's "nearest, lowest scene index on ties" does not depend on visit order), any
+// hit = OR.  Helpers prune with the owner's best distance so far (read from LDS at every node step), so work stolen
+// ahead of a near hit dies quickly.  Same hits, same bits; only the test COUNTS differ from the private walk (a helper
+// may test a box the owner would have pruned a moment later).
+//
+// Per-wave LDS ("share region", behind the wave's stack region): [0,64) donor table of a steal round, [64,192) the
+// owners' best keys (u64: t bits << 32 | scene id), [192,320) ref + material of the key's holder, [320,384) any-hit flags.
+constexpr unsigned long long kShareNoHit = 0x7F7FFFFFFFFFFFFFull;      // t = FLT_MAX, id = none
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wave execute in program order; this only keeps the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t share_lane_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ float shfl_f(float v, uint32_t src) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src << 2), __float_as_int(v)));
+}
+__device__ __forceinline__ uint32_t shfl_u(uint32_t v, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
+}
+
+// One steal round (all 64 lanes, converged): pairs the k-th idle lane with the k-th lane that has a pending stack
+// entry.  Returns true in the lanes that took work; their `cur` is the stolen node and ray / slab constants / owner
+// are the victim's.  `limit` travels too (closest hit: the victim's best distance; any hit: its distance bound).
+__device__ __forceinline__ bool steal_round(uint32_t* stack_region, uint32_t* share, uint32_t lane, uint64_t busy, uint64_t donors,
+                                            int32_t& cur, int& sp, int& bot, Ray& r, SlabRay& s, float& limit, uint32_t& owner) {
+    const uint64_t idle = ~busy;
+    const bool is_idle = ((idle >> lane) & 1ull) != 0, is_donor = ((donors >> lane) & 1ull) != 0;
+    const uint32_t n_i = (uint32_t)__popcll(idle), n_d = (uint32_t)__popcll(donors), n = n_i < n_d ? n_i : n_d;
+    const uint32_t rank_i = share_lane_rank(idle), rank_d = share_lane_rank(donors);
+    volatile uint32_t* tab = share;
+    const bool robbed = is_donor && rank_d < n;
+    if (robbed) tab[rank_d] = lane;
+    wave_lds_fence();
+    const bool thief = is_idle && rank_i < n;
+    const uint32_t victim = thief ? tab[rank_i] : lane;
+    const int v_bot = (int)shfl_u((uint32_t)bot, victim);
+    const Ray vr = {mk(shfl_f(r.o.x, victim), shfl_f(r.o.y, victim), shfl_f(r.o.z, victim)),
+                    mk(shfl_f(r.d.x, victim), shfl_f(r.d.y, victim), shfl_f(r.d.z, victim))};
+    const SlabRay vs = {shfl_f(s.kx, victim), shfl_f(s.ky, victim), shfl_f(s.kz, victim),
+                        shfl_f(s.ix, victim), shfl_f(s.iy, victim), shfl_f(s.iz, victim)};
+    const float v_limit = shfl_f(limit, victim);
+    const uint32_t v_owner = shfl_u(owner, victim);
+    if (thief) {
+        cur = (int32_t)reinterpret_cast<volatile uint32_t*>(stack_region)[(uint32_t)v_bot * 64u + victim];
+        sp = 0; bot = 0; r = vr; s = vs; limit = v_limit; owner = v_owner;
+    }
+    if (robbed) { bot++; if (bot == sp) { bot = 0; sp = 0; } }
+    wave_lds_fence();
+    return thief;
+}
+
+// publish a lane's best hit for the ray it works on: key by 64-bit minimum, ref / material by whoever holds the minimum
+__device__ __forceinline__ unsigned long long share_key(const Hit& h) {
+    // (t + 0.0f: -0.0f and +0.0f compare equal in the reference's "t < closest_t", so they must give one key)
+    return ((unsigned long long)__float_as_uint(h.t + 0.0f) << 32) | (unsigned long long)h.sid;
+}
+__device__ __forceinline__ void share_publish(uint32_t* share, uint32_t owner, const Hit& h) {
+    if (h.ref == 0xFFFFFFFFu) return;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(share + 64);
+    const unsigned long long key = share_key(h);
+    atomicMin(&keys[owner], key);
+    if (reinterpret_cast<volatile unsigned long long*>(keys)[owner] == key)
+        reinterpret_cast<volatile unsigned long long*>(share + 192)[owner] = (unsigned long long)h.ref | ((unsigned long long)h.mat << 32);
+}
+
+// closest hit, work shared among the lanes of the wave.  Must be called by all 64 lanes together; `active` = this lane
+// has a ray.  Same result as closest_hit().
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit_shared(const LaunchParams& P, const GlobalScene& sv, const Ray& ray, bool active,
+                                                  TravStack region, uint32_t* share, Ctr& ctr) {
+    Hit best; best.t = 3.402823466e+38f; best.ref = 0xFFFFFFFFu; best.sid = 0xFFFFFFFFu; best.mat = 0;
+    if (active) {
+        if (COUNT) ctr.closest++;
+        for (uint32_t i = 0; i < P.n_planes; i++) {
+            PlaneRec pl = P.planes[i];
+            float t;
+            if (COUNT) ctr.pln++;
+            if (hit_plane(ray, mk(pl.nx, pl.ny, pl.nz), pl.d, t)) {
+                PrimMeta m = P.plane_meta[i];
+                if (t < best.t || (t == best.t && m.scene_id < best.sid)) {
+                    best.t = t; best.ref = (3u << kRefKindShift) | i; best.sid = m.scene_id; best.mat = m.material;
+                }
+            }
+        }
+    }
+    const uint32_t lane = region.lane;
+    Ray r = ray;
+    SlabRay s = make_slab(sv, r);
+    uint32_t* refs = region.region + lane;
+    int sp = 0, bot = 0;
+    int32_t cur = active ? 0 : P3D_DONE;
+    uint32_t owner = lane;
+    bool shared = false;                       // wave-uniform: some lane of this wave has taken over work in this query
+    volatile uint32_t* key_hi = share + 64;    // high dword of keys[o] at [2 * o + 1]
+    const uint32_t min_idle = P.share_min_idle;
+    for (;;) {
+        const uint64_t busy = __ballot(cur != P3D_DONE);
+        if (busy == 0) break;
+        if (64u - (uint32_t)__popcll(busy) >= min_idle) {
+            const uint64_t donors = __ballot(cur != P3D_DONE && sp > bot);
+            if (donors != 0) {
+                if (!shared) {
+                    reinterpret_cast<volatile unsigned long long*>(share + 64)[lane] = kShareNoHit;
+                    shared = true;
+                    wave_lds_fence();
+                }
+                // an idle lane's result so far belongs to the ray it worked on: hand it in before taking other work
+                if (cur == P3D_DONE) { share_publish(share, owner, best); best.ref = 0xFFFFFFFFu; }
+                wave_lds_fence();
+                float limit = best.t;
+                const bool took = steal_round(region.region, share, lane, busy, donors, cur, sp, bot, r, s, limit, owner);
+                if (took) { best.t = limit; best.sid = 0xFFFFFFFFu; best.mat = 0; }
+            }
+        }
+        if (cur >= 0) {
+            float tl = best.t;
+            if (shared) tl = fminf(tl, __uint_as_float(key_hi[2u * owner + 1u]));   // what any lane found for this ray so far
+            float tn0, tn1; bool h0, h1; int32_t c0, c1;
+            node_test(sv, s, cur, tl, h0, h1, tn0, tn1, c0, c1);
+            if (COUNT) ctr.box += 2;
+            if (h0 && h1) {
+                const bool swap = tn1 < tn0;
+                refs[sp * 64] = (uint32_t)(swap ? c0 : c1); sp++;
+                cur = swap ? c1 : c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else if (sp > bot) { sp--; cur = (int32_t)refs[sp * 64]; if (sp == bot) { sp = 0; bot = 0; } }
+            else cur = P3D_DONE;
+        } else if (cur != P3D_DONE) {
+            const float before = best.t; const uint32_t sid_before = best.sid;
+            leaf_closest<COUNT>(P, sv, r, cur, best, ctr);
+            if (shared && (best.t != before || best.sid != sid_before))          // let the other lanes of this ray prune with it
+                atomicMin(&reinterpret_cast<unsigned long long*>(share + 64)[owner], share_key(best));
+            if (sp > bot) { sp--; cur = (int32_t)refs[sp * 64]; if (sp == bot) { sp = 0; bot = 0; } }
+            else cur = P3D_DONE;
+        }
+    }
+    if (shared) {
+        wave_lds_fence();
+        share_publish(share, owner, best);
+        wave_lds_fence();
+        const unsigned long long k = reinterpret_cast<volatile unsigned long long*>(share + 64)[lane];
+        const unsigned long long aq = reinterpret_cast<volatile unsigned long long*>(share + 192)[lane];
+        const uint2 a = make_uint2((uint32_t)aq, (uint32_t)(aq >> 32));
+        best.t = 3.402823466e+38f; best.ref = 0xFFFFFFFFu; best.sid = 0xFFFFFFFFu; best.mat = 0;
+        if (active && k != kShareNoHit) { best.t = __uint_as_float((uint32_t)(k >> 32)); best.sid = (uint32_t)k; best.ref = a.x; best.mat = a.y; }
+        wave_lds_fence();
+    }
+    return best;
+}
+
+// any hit with t < tmax (bounded) or at all, work shared like closest_hit_shared().  All 64 lanes together; `need` =
+// this lane has a shadow ray.  Same result as any_hit().
+template <bool COUNT>
+__device__ __forceinline__ bool any_hit_shared(const LaunchParams& P, const GlobalScene& sv, const Ray& ray, bool need, bool bounded,
+                                               float tmax, TravStack region, uint32_t* share, Ctr& ctr) {
+    bool occ_own = false;
+    if (need) {
+        if (COUNT) ctr.shadow++;
+        if (P.n_planes) {
+            const bool gate = !bounded || ref_unit_box_hit(ray);
+            for (uint32_t i = 0; i < P.n_planes; i++) {
+                PlaneRec pl = P.planes[i];
+                float t;
+                if (gate && !occ_own) {
+                    if (COUNT) ctr.pln++;
+                    if (hit_plane(ray, mk(pl.nx, pl.ny, pl.nz), pl.d, t) && (!bounded || t < tmax)) occ_own = true;
+                }
+            }
+        }
+    }
+    const uint32_t lane = region.lane;
+    Ray r = ray;
+    SlabRay s = make_slab(sv, r);
+    float limit = bounded ? tmax : 3.402823466e+38f;
+    uint32_t* refs = region.region + lane;
+    int sp = 0, bot = 0;
+    int32_t cur = (need && !occ_own) ? 0 : P3D_DONE;
+    uint32_t owner = lane;
+    bool shared = false;
+    volatile uint32_t* flags = share + 320;
+    const uint32_t min_idle = P.share_min_idle;
+    for (;;) {
+        const uint64_t busy = __ballot(cur != P3D_DONE);
+        if (busy == 0) break;
+        if (64u - (uint32_t)__popcll(busy) >= min_idle) {
+            const uint64_t donors = __ballot(cur != P3D_DONE && sp > bot);
+            if (donors != 0) {
+                if (!shared) { flags[lane] = occ_own ? 1u : 0u; shared = true; wave_lds_fence(); }
+                // a ray some lane has found an occluder for needs no more work
+                if (cur != P3D_DONE && flags[owner] != 0u) { cur = P3D_DONE; sp = 0; bot = 0; }
+                const uint64_t busy2 = __ballot(cur != P3D_DONE), donors2 = __ballot(cur != P3D_DONE && sp > bot);
+                if (donors2 != 0) (void)steal_round(region.region, share, lane, busy2, donors2, cur, sp, bot, r, s, limit, owner);
+            }
+        }
+        if (cur >= 0) {
+            float tn0, tn1; bool h0, h1; int32_t c0, c1;
+            node_test(sv, s, cur, limit, h0, h1, tn0, tn1, c0, c1);
+            if (COUNT) ctr.box += 2;
+            if (h0 && h1) {
+                const bool swap = tn1 < tn0;
+                refs[sp * 64] = (uint32_t)(swap ? c0 : c1); sp++;
+                cur = swap ? c1 : c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else if (sp > bot) { sp--; cur = (int32_t)refs[sp * 64]; if (sp == bot) { sp = 0; bot = 0; } }
+            else cur = P3D_DONE;
+        } else if (cur != P3D_DONE) {
+            if (leaf_any<COUNT>(P, sv, r, cur, bounded, limit, ctr)) {
+                if (owner == lane) occ_own = true;
+                if (shared) flags[owner] = 1u;
+                cur = P3D_DONE; sp = 0; bot = 0;
+            } else if (sp > bot) { sp--; cur = (int32_t)refs[sp * 64]; if (sp == bot) { sp = 0; bot = 0; } }
+            else cur = P3D_DONE;
+        }
+    }
+    if (shared) {
+        wave_lds_fence();
+        occ_own = occ_own || flags[lane] != 0u;
+        wave_lds_fence();
+    }
+    return need && occ_own;
 }
 
 
