@@ -280,4 +280,24 @@ hipError_t build_lbvh_device(const std::vector<BuildPrim>& prims, const BvhOptio
     return done(hipSuccess);
 }
 
+// ------------------------------------------------------------------ tile order of the persistent tile schedule
+// "Heaviest first": tiles sorted by the duration the previous frames measured for them (p3d_kernels.hip: wf_tile_kernel
+// writes LaunchParams::tile_cost).  Persistent workgroups that draw tiles in that order finish together; drawn row by row,
+// the expensive tiles of a frame are started late and the launch ends with a few workgroups still on them (dragon: 1.29 ms
+// against 0.76 for the same tile durations list-scheduled heaviest first, profiles/r03_tile_timeline.txt).
+__global__ void iota_kernel(uint32_t* v, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+// temp_bytes == 0: only reports the temporary storage the sort needs
+hipError_t sort_tiles_by_cost(const uint32_t* cost, uint32_t* cost_sorted, uint32_t* iota, uint32_t* order, uint32_t n,
+                              void* temp, size_t& temp_bytes, hipStream_t stream) {
+    if (temp == nullptr)
+        return hipcub::DeviceRadixSort::SortPairsDescending(nullptr, temp_bytes, cost, cost_sorted, iota, order, (int)n, 0, 32, stream);
+    hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, iota, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipcub::DeviceRadixSort::SortPairsDescending(temp, temp_bytes, cost, cost_sorted, iota, order, (int)n, 0, 32, stream);
+}
+
 }  // namespace p3d

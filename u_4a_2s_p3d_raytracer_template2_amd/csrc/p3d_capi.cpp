@@ -40,6 +40,8 @@ hipError_t launch_deinterleave(const void* gathered, void* frames, int res_x, in
                                size_t out_stride, hipStream_t stream);
 hipError_t build_lbvh_device(const std::vector<BuildPrim>& prims, const BvhOptions& opt, NodePair* d_nodes,
                              uint32_t* d_refs, BvhStats& stats, hipStream_t stream);
+hipError_t sort_tiles_by_cost(const uint32_t* cost, uint32_t* cost_sorted, uint32_t* iota, uint32_t* order, uint32_t n,
+                              void* temp, size_t& temp_bytes, hipStream_t stream);
 hipError_t launch_debug_intersect(uint32_t n, const uint32_t* type, const float* prim12, const float* origin,
                                   const float* dir, int32_t* hit, float* t, float* normal, hipStream_t stream);
 }  // namespace p3d
@@ -153,6 +155,16 @@ struct p3d_scene {
     // tile schedule: (resident workgroups) x (one 16x16 tile's worst-case queues), and the tile counter + exit
     // ticket the kernel re-arms itself (zeroed once, at allocation)
     RawBuf tile_ws, tile_ctrl;
+    // "heaviest tile first" for scenes read from HBM: per-tile durations written by the tile kernel, and the order made of
+    // them after the first frame of a configuration and every kTileOrderPeriod frames from then on (all on the frame's stream)
+    struct {
+        RawBuf cost, sorted, iota, order, temp;
+        size_t temp_bytes = 0;
+        int32_t key[8] = {0, 0, 0, -1, -1, 0, 0, 0};
+        bool valid = false;          // `order` holds an order for `key`
+        int frames = 0;              // frames rendered since it was made
+    } tile_lpt;
+    bool tile_lpt_enabled = true;
     struct { uint32_t key = 0xFFFFFFFFu; size_t lds = 0; int blocks = 0; } tile_occ;   // cached occupancy query
     struct { uint32_t key = 0xFFFFFFFFu; uint32_t stack = 0; unsigned waves = 0, primary_waves = 0; } wf_occ;                 // ... of the deeper-level kernel
     hipStream_t lane_stream[kLanes] = {nullptr, nullptr, nullptr, nullptr};
@@ -186,6 +198,7 @@ struct p3d_scene {
     int resolve_blocks_per_shard = 16;   // a resolve launch is latency-bound: few nodes per thread, many threads
     int fused_resolve_shard_px = 8192;   // frames with at most this many pixels per shard resolve all levels in one launch
     bool pair_mode = true;               // the last level combines sibling rays with their parent (LaunchParams::wf_pair_in)
+    bool fuse_last = false;              // LDS scenes: level D - 1 traces level D itself (LaunchParams::wf_fuse_last); replaces pair mode
     uint32_t dbg_skip = 0;               // diagnostic builds only (LaunchParams::dbg_skip)
     unsigned long long* dbg_stamps = nullptr; int dbg_stamp_level = 1;
     int occupancy = 0;     // 0 = compiler default register budget, else 5 / 6 / 8 waves per SIMD
@@ -304,6 +317,9 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     if (const char* e = getenv("P3D_FUSED_RESOLVE_PX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 24)) s->fused_resolve_shard_px = v; }
     s->pair_mode = getenv("P3D_NO_PAIR_MODE") == nullptr;
     s->verbose = getenv("P3D_VERBOSE") != nullptr;
+    if (const char* e = getenv("P3D_FUSE_LAST")) s->fuse_last = atoi(e) != 0;
+    if (const char* e = getenv("P3D_TILE_LPT")) s->tile_lpt_enabled = atoi(e) != 0;
+    if (const char* e = getenv("P3D_OCC")) { int v = atoi(e); if (v == 0 || v == 5 || v == 6) s->occupancy = v; }
     if (const char* e = getenv("P3D_TRI_STRIDE")) s->tri_quads = atoi(e) == 64 ? 4u : 3u;
     if (const char* e = getenv("P3D_PRIMARY_TILES")) { int v = atoi(e); if (v >= 1 && v <= 8) s->primary_tiles_per_wg = v; }
     if (const char* e = getenv("P3D_PRIMARY_WG_WAVES")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) s->primary_wg_waves = v; }
@@ -400,6 +416,7 @@ int p3d_scene_destroy(p3d_scene* s) {
     s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release(); s->ray_tab.release();
     for (auto& w : s->ws) w.release();
     s->wf_planes.release(); s->tile_ws.release(); s->tile_ctrl.release();
+    s->tile_lpt.cost.release(); s->tile_lpt.sorted.release(); s->tile_lpt.iota.release(); s->tile_lpt.order.release(); s->tile_lpt.temp.release();
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     for (int i = 1; i < kLanes; i++) {
         if (s->ev_join[i]) (void)hipEventDestroy(s->ev_join[i]);
@@ -498,7 +515,11 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
     const unsigned resident_waves = s->wf_occ.waves;
     // pair mode (LaunchParams::wf_pair_in): the last level combines sibling rays with their parent in registers, so
     // level D - 1 needs no resolve launch
-    const bool pair_mode = D >= 2 && s->pair_mode;
+    // fused last level (LaunchParams::wf_fuse_last): the launch of level D - 1 traces level D itself; takes the place of pair mode
+    const bool fuse_last = D >= 2 && s->fuse_last && lds;
+    const bool pair_mode = D >= 2 && s->pair_mode && !fuse_last;
+    const int last_launch = fuse_last ? D - 1 : D;               // deepest level that gets a launch of its own
+    P.wf_fuse_last = (fuse_last && D == 2) ? 1 : 0;
     P.wf_pair_in = 0; P.wf_pair_out = (pair_mode && D == 2) ? 1 : 0;
     P.wf_nodes_grand = nullptr; P.wf_ncap_grand = 0;
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], stream));
@@ -526,8 +547,9 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
         HIP_TRY(launch_wf_primary(P1, count, lds, walk, occ, stream));
     }
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], stream));
-    for (int l = 2; l <= D; l++) {
+    for (int l = 2; l <= last_launch; l++) {
         P.wf_level = l;
+        P.wf_fuse_last = (fuse_last && l == D - 1) ? 1 : 0;
         P.wf_rays_in = rays(l); P.wf_count_in = qcount(l); P.wf_cap_in = cap(l);
         P.wf_rays_out = rays(l + 1); P.wf_count_out = qcount(l + 1); P.wf_cap_out = cap(l + 1);
         P.wf_rng_in = rng(l); P.wf_rng_out = rng(l + 1);
@@ -542,8 +564,8 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
         waves = std::max<unsigned>(kShards * 4, (waves / (kShards * 4)) * (kShards * 4));   // whole workgroups per shard
         HIP_TRY(launch_wf_secondary(P, count, lds, walk, occ, waves, stream));
     }
-    P.wf_pair_in = P.wf_pair_out = 0;
-    const int top = pair_mode ? D - 2 : D - 1;            // highest level that still has to be resolved by a launch
+    P.wf_pair_in = P.wf_pair_out = 0; P.wf_fuse_last = 0;
+    const int top = (pair_mode || fuse_last) ? D - 2 : D - 1;            // highest level that still has to be resolved by a launch
     if (top >= 2 && shard_px <= (size_t)s->fused_resolve_shard_px) {
         // small frame (a rank's share of a tiled frame): all resolve levels in ONE launch, a workgroup per shard
         ResolveLevels R;
@@ -725,12 +747,15 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     const size_t slot_rng = stochastic ? (size_t)tile_ray_entries(D) * sizeof(uint32_t) : 0;
     const size_t slot_bytes = ((slot_rays + slot_nodes + slot_rng + 255) / 256) * 256 + 256;
     int tile_blocks = 0;
+    // register budget of the tile kernel: scenes read from HBM run it at 5 waves per SIMD (with the work-sharing walk the
+    // default allocation is 129 VGPRs: one over the step to 3 waves per SIMD, i.e. 3 workgroups per CU instead of 4)
+    const int tile_occ = s->occupancy ? s->occupancy : (lds_scene ? 0 : 5);
     bool tile_ok = tile_kernel_lds_bytes(PT, lds_scene) <= kMaxLdsBytes && D <= 16;
     if (tile_ok) {
-        const uint32_t okey = (count ? 1u : 0u) | (lds_scene ? 2u : 0u) | ((uint32_t)walk << 2) | (stochastic ? 16u : 0u) | ((uint32_t)s->occupancy << 5);
+        const uint32_t okey = (count ? 1u : 0u) | (lds_scene ? 2u : 0u) | ((uint32_t)walk << 2) | (stochastic ? 16u : 0u) | ((uint32_t)tile_occ << 5);
         const size_t olds = tile_kernel_lds_bytes(PT, lds_scene);
         if (s->tile_occ.key != okey || s->tile_occ.lds != olds) {
-            HIP_TRY(tile_kernel_resident_blocks(PT, count, lds_scene, walk, s->occupancy, &s->tile_occ.blocks));
+            HIP_TRY(tile_kernel_resident_blocks(PT, count, lds_scene, walk, tile_occ, &s->tile_occ.blocks));
             s->tile_occ.key = okey; s->tile_occ.lds = olds;
         }
         tile_blocks = s->tile_occ.blocks;
@@ -861,11 +886,47 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         PT.tw_rays_off = 0; PT.tw_nodes_off = (uint32_t)slot_rays; PT.tw_rng_off = (uint32_t)(slot_rays + slot_nodes);
         if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
+        // heaviest tile first (scenes read from HBM: their tiles differ by orders of magnitude; LDS scenes' do not)
+        bool lpt_sort = false;
+        if (!lds_scene && s->tile_lpt_enabled && PT.n_tiles >= 64) {
+            auto& L = s->tile_lpt;
+            const int32_t lkey[8] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world, (int32_t)prm->features};
+            hipStreamCaptureStatus lcap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(s->stream, &lcap);
+            if (memcmp(lkey, L.key, sizeof lkey) != 0) {
+                if (lcap == hipStreamCaptureStatusNone) {          // (allocations: not while a capture is open)
+                    const size_t nb = (size_t)PT.n_tiles * sizeof(uint32_t);
+                    HIP_TRY(L.cost.ensure(nb)); HIP_TRY(L.sorted.ensure(nb)); HIP_TRY(L.iota.ensure(nb)); HIP_TRY(L.order.ensure(nb));
+                    size_t tb = 0;
+                    HIP_TRY(sort_tiles_by_cost(nullptr, nullptr, nullptr, nullptr, (uint32_t)PT.n_tiles, nullptr, tb, s->stream));
+                    HIP_TRY(L.temp.ensure(tb)); L.temp_bytes = tb;
+                    HIP_TRY(launch_clear_words((uint32_t*)L.cost.p, (uint32_t)PT.n_tiles, s->stream));
+                    memcpy(L.key, lkey, sizeof lkey); L.valid = false; L.frames = 0;
+                } else {
+                    L.valid = false; L.key[3] = -1;
+                }
+            }
+            if (memcmp(lkey, L.key, sizeof lkey) == 0) {
+                PT.tile_cost = (uint32_t*)L.cost.p;
+                PT.tile_order = L.valid ? (const uint32_t*)L.order.p : nullptr;
+                constexpr int kTileOrderPeriod = 64;
+                lpt_sort = lcap == hipStreamCaptureStatusNone && (!L.valid || L.frames >= kTileOrderPeriod);
+            }
+        }
         if (s->verbose)
             fprintf(stderr, "p3d: tile schedule: %d workgroups (occupancy query: %d on the device), %zu B LDS each, %zu B workspace slot, %d tiles\n",
                     tile_blocks, s->tile_occ.blocks, tile_kernel_lds_bytes(PT, lds_scene), slot_bytes, PT.n_tiles);
-        HIP_TRY(launch_wf_tile(PT, count, lds_scene, walk, s->occupancy, (unsigned)tile_blocks, s->stream));
+        HIP_TRY(launch_wf_tile(PT, count, lds_scene, walk, tile_occ, (unsigned)tile_blocks, s->stream));
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream));
+        if (PT.tile_cost) {
+            auto& L = s->tile_lpt;
+            L.frames++;
+            if (lpt_sort) {          // the order the NEXT frames draw their tiles in, from what this one measured
+                HIP_TRY(sort_tiles_by_cost((const uint32_t*)L.cost.p, (uint32_t*)L.sorted.p, (uint32_t*)L.iota.p, (uint32_t*)L.order.p,
+                                           (uint32_t)PT.n_tiles, L.temp.p, L.temp_bytes, s->stream));
+                L.valid = true; L.frames = 0;
+            }
+        }
     } else if (use_tree) {
         if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));
         P.wf_tile_row0 = 0; P.wf_tile_rows = P.tiles_y;

@@ -145,6 +145,7 @@ struct LaunchParams {
     // rays all return at once, RT/main.cpp:632-634 -- combines each pair with its parent's parked record in registers and
     // hands the result to the GRANDPARENT (level D - 2 nodes, or the pixel): no resolve launch for level D - 1.
     int32_t wf_pair_in, wf_pair_out;
+    int32_t wf_fuse_last;             // this launch is level D - 1 and traces its nodes' children (level D) itself: fuse_last_level()
     NodeRec* wf_nodes_grand; uint32_t wf_ncap_grand;
     NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
     float* wf_planes; uint64_t wf_plane_stride;                   // [sample][local px][3] clamped sample colours; floats per plane
@@ -166,6 +167,9 @@ struct LaunchParams {
     uint8_t*  tw_base; uint64_t tw_slot_bytes;
     uint32_t* tw_ctrl;
     uint32_t  tw_rays_off, tw_nodes_off, tw_rng_off;     // byte offsets of the three regions inside a slot
+    // the k-th tile a workgroup draws is tile_order[k] (nullptr: k); tile_cost[tile] = how long the tile took, in 10 ns
+    // ticks, for the next ordering (bvh_device.hip: sort_tiles_by_cost).  Scenes read from HBM only.
+    const uint32_t* tile_order; uint32_t* tile_cost;
 };
 
 // Every level of a pass for the fused resolve launch (small frames / shards, wf_resolve_fused_kernel): level l's

@@ -263,6 +263,37 @@ __device__ __forceinline__ void combine_pair(const LaunchParams& P, const Shard&
     dst[0] = ret.x; dst[1] = ret.y; dst[2] = ret.z;
 }
 
+// Last level fused into the launch of level D - 1 (LaunchParams::wf_fuse_last): every ray of level D returns at once
+// (RT/main.cpp:632-634), so the lane that shaded a level-(D-1) node traces that node's one or two children ITSELF, right
+// there, and combines them with the node in registers -- "color += reflection_color * KR * specColor + refraction_color *
+// (1 - KR)", RT/main.cpp:719; a child never traced adds zero -- no queue, no parked record, no launch for level D.
+// Must be reached by all lanes of the wave together.  Returns the node as a terminal one.
+template <bool COUNT, int WALK, class SV, bool STOCH>
+__device__ __forceinline__ NodeOut fuse_last_level(const LaunchParams& P, const SV& sv, const NodeOut& o, bool live, int level, float ior_1,
+                                                   const TravCtx& tc, Ctr& ctr) {
+    const bool parent = live && !o.terminal;
+    if (__ballot(parent) == 0) return o;
+    V3 refl_ret = mk(0.0f, 0.0f, 0.0f), refr_ret = refl_ret;
+    _Pragma("clang loop unroll(disable)")
+    for (int c = 0; c < 2; c++) {
+        const bool a = parent && (c == 0 ? o.has_refl : o.has_refr);
+        if (__ballot(a) == 0) continue;
+        Ray cr; cr.o = c == 0 ? o.refl.o : o.refr.o; cr.d = c == 0 ? o.refl.d : o.refr.d;
+        const float cior = c == 0 ? ior_1 : o.newIor;                    // the reflection child keeps ior_1
+        const uint32_t crng = c == 0 ? o.rng_refl : o.rng_refr;
+        const Hit ch = find_closest<COUNT, WALK>(P, sv, cr, a, tc, ctr);
+        const NodeOut co = shade_hit<COUNT, WALK, SV, STOCH>(P, sv, cr, ch, a, level + 1, cior, tc, ctr, crng);
+        if (a) { if (c == 0) refl_ret = co.ret; else refr_ret = co.ret; }
+    }
+    NodeOut t = o;
+    if (parent) {
+        const Mtl M = load_material(sv, o.mat);
+        t.terminal = true;
+        t.ret = combine_node(o.color, o.KR, M.spec, refl_ret, refr_ret);
+    }
+    return t;
+}
+
 // this wave's traversal stack: after the (optional) scene copy, one region per wave
 template <bool LDS>
 __device__ __forceinline__ TravCtx wave_stack(const LaunchParams& P, uint32_t extra_dwords_per_wave, uint32_t** wave_base = nullptr) {
@@ -345,7 +376,8 @@ __global__ __launch_bounds__(LDS ? 1024 : 64) P3D_OCC(OCC) void wf_primary_kerne
         // the random stream of a pixel sample is keyed by the pixel's place in the FULL frame, so a frame
         // sharded over several GPUs draws the same numbers as on one
         const uint32_t rng = STOCH ? rng_mix(rng_mix(P.seed, (uint32_t)(y * P.res_x + x)), (uint32_t)P.wf_sample) : 0u;
-        const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr, rng);
+        NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr, rng);
+        if (P.wf_fuse_last) o = fuse_last_level<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, o, valid, 1, 1.0f, tc, ctr);
         stamp(P, tile, 3);
         emit(P, sh, 1, valid, (uint32_t)p, 1.0f, o);
         stamp(P, tile, 4);
@@ -416,8 +448,9 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
             if (stamps_on(P) && st1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_wave(P, wave_id, 1); }
             const Hit h = find_closest<COUNT, WALK>(P, sv, ray, live, tc, ctr);
             stamp_wave(P, wave_id, 2, st1);
-            const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
-                                                                                    ctr, rng);
+            NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
+                                                                              ctr, rng);
+            if (P.wf_fuse_last) o = fuse_last_level<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, o, live, P.wf_level, ior_1, tc, ctr);
             stamp_wave(P, wave_id, 3, st1);
             if (P.wf_pair_in) combine_pair(P, sh, live, link, o);
             else emit(P, sh, P.wf_level, live, link, ior_1, o);
@@ -463,8 +496,9 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
         const bool live = valid && link != kPairEmpty;
         const Hit h = find_closest<COUNT, WALK>(P, sv, ray, live, tc, ctr);
         stamp_wave(P, wave_id, 2, st1);
-        const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
-                                                                                ctr, rng);
+        NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
+                                                                          ctr, rng);
+        if (P.wf_fuse_last) o = fuse_last_level<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, o, live, P.wf_level, ior_1, tc, ctr);
         stamp_wave(P, wave_id, 3, st1);
         if (P.wf_pair_in) combine_pair(P, sh, live, link, o);
         else emit(P, sh, P.wf_level, live, link, ior_1, o);
@@ -623,15 +657,24 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
     const int D = P.max_depth, ns = P.spp > 0 ? P.spp * P.spp : 1;
     uint32_t my_pixels = 0;
     int prev_tile = -1;
+    unsigned long long t_tile = 0;
     for (;;) {
         if (tid == 0) T->tile = atomicAdd(&P.tw_ctrl[0], 1u);
         __syncthreads();
-        const int tile = (int)T->tile;
-        if (tile >= P.n_tiles) break;                            // workgroup-uniform
-        if (P.dbg_stamps && tid == 0) {                          // diagnostic: one record per TILE (0 start, 1 end, 2 workgroup)
-            if (prev_tile >= 0) P.dbg_stamps[(size_t)prev_tile * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-            P.dbg_stamps[(size_t)tile * 8] = __builtin_amdgcn_s_memrealtime();
-            P.dbg_stamps[(size_t)tile * 8 + 2] = blockIdx.x;
+        if ((int)T->tile >= P.n_tiles) {                         // workgroup-uniform
+            if (P.tile_cost && tid == 0 && prev_tile >= 0) P.tile_cost[prev_tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
+            break;
+        }
+        const int tile = P.tile_order ? (int)P.tile_order[T->tile] : (int)T->tile;     // (heaviest first, once measured)
+        if (tid == 0 && (P.tile_cost || P.dbg_stamps)) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (P.tile_cost && prev_tile >= 0) P.tile_cost[prev_tile] = (uint32_t)(now - t_tile);
+            if (P.dbg_stamps) {                                  // diagnostic: one record per TILE (0 start, 1 end, 2 workgroup)
+                if (prev_tile >= 0) P.dbg_stamps[(size_t)prev_tile * 8 + 1] = now;
+                P.dbg_stamps[(size_t)tile * 8] = now;
+                P.dbg_stamps[(size_t)tile * 8 + 2] = blockIdx.x;
+            }
+            t_tile = now;
         }
         prev_tile = tile;
         X.tx = tile % P.tiles_x; X.ty = tile / P.tiles_x;
