@@ -152,6 +152,10 @@ typedef struct p3d_render_params {
                                     layout): the caller uploaded the sample array once instead of per call    */
 #define P3D_FLAG_PROFILE 16u     /* bracket the frame and its dominant kernel (the level-1 /
                                     tree launch) with HIP events for p3d_get_profile()           */
+#define P3D_FLAG_PRIVATE_WALK 8u /* scenes read from HBM: every lane walks the BVH for its own ray only.  Without it the
+                                    lanes of a wave may SHARE their walks -- idle lanes take over pending subtrees of busy
+                                    ones, results merged by minimum over (t, scene id) / OR: same hits, same bits -- and
+                                    whether they do is part of the measured schedule choice                              */
 #define P3D_FLAG_PACKET_WALK 256u /* wave-wide (packet) BVH walk for trees of up to 64 node pairs: node and primitive
                                     records fetched once per wave, a node visited when any lane's slab test passes.
                                     Same results as the default per-lane walk; measured slower since the leaves

@@ -37,10 +37,17 @@ def test_schedule_pick_is_measured_and_invisible():
     ds = P.DeviceScene.from_host(hs)
     assert ds.stats()["device_bytes"] > (2 << 20)
     seen, frames = [], []
-    for _ in range(8):
+    for _ in range(14):
         frames.append(ds.render(cam, max_depth=4, accel=2))
         seen.append(ds.last_schedule())
-    # two frames of each schedule (the first untimed: code-object load, workspace allocation), then the fastest for good
+    # two frames of each schedule (the first untimed: code-object load, workspace allocation) with the lanes of a wave
+    # sharing their walks, the same again with private walks, then the fastest of the six for good
+    assert seen[:12] == ["wavefront", "wavefront", "tree", "tree", "tile", "tile"] * 2 and seen[12] == seen[13]
+    # ... and with private walks demanded there are only the three schedules to measure
+    seen = []
+    for _ in range(8):
+        frames.append(ds.render(cam, max_depth=4, accel=2, private_walk=True))
+        seen.append(ds.last_schedule())
     assert seen[:6] == ["wavefront", "wavefront", "tree", "tree", "tile", "tile"] and seen[6] == seen[7]
     for f in frames[1:]:
         assert np.array_equal(f["rgb32f"], frames[0]["rgb32f"], equal_nan=True)

@@ -123,7 +123,10 @@ def test_schedules_and_scene_placements_are_bit_identical():
         a = gpu_render(CASES[name], counters=True, wavefront=True)
         for kw in (dict(tree=True), dict(no_lds=True), dict(tree=True, no_lds=True), dict(wavefront=True, packet=True),
                    dict(wavefront=True, packet=True, no_lds=True), dict(tile=True), dict(tile=True, no_lds=True),
-                   dict(tile=True, packet=True), dict(tile=True, packet=True, no_lds=True), dict(wavefront=True, no_lds=True)):
+                   dict(tile=True, packet=True), dict(tile=True, packet=True, no_lds=True), dict(wavefront=True, no_lds=True),
+                   # scenes read from HBM: lanes sharing their walks (default when forced) vs every lane for itself
+                   dict(wavefront=True, no_lds=True, private_walk=True), dict(tile=True, no_lds=True, private_walk=True),
+                   dict(tree=True, no_lds=True, private_walk=True)):
             b = gpu_render(CASES[name], counters=True, **kw)
             assert np.array_equal(a["rgb8"], b["rgb8"]) and np.array_equal(a["hit_id"], b["hit_id"]), (name, kw)
             assert np.array_equal(a["rgb32f"].view(np.uint32), b["rgb32f"].view(np.uint32)), (name, kw)

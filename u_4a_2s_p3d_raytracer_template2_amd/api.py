@@ -14,6 +14,7 @@ ACCEL_NONE, ACCEL_GRID, ACCEL_BVH = 0, 1, 2
 FLAG_COUNTERS = 1
 FLAG_TREE_KERNEL = 2
 FLAG_NO_LDS_SCENE = 4
+FLAG_PRIVATE_WALK = 8
 FLAG_PROFILE = 16
 FLAG_WAVEFRONT = 32
 FLAG_TILE_KERNEL = 64
@@ -368,7 +369,7 @@ class DeviceScene:
         _check(lib().p3d_get_counters(self.h, C.byref(c)), "p3d_get_counters")
         return c.as_dict()
 
-    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False):
+    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False, private_walk=False):
         p = RenderParams()
         p.max_depth, p.accel, p.spp = int(max_depth), int(accel), int(spp)
         p.samples = samples.ctypes.data_as(C.POINTER(C.c_float)) if samples is not None else None
@@ -377,11 +378,11 @@ class DeviceScene:
         p.row_block, p.rank, p.world = int(row_block), int(rank), int(world)
         p.features = (FEATURE_SOFT_SHADOW if soft_shadow else 0) | (FEATURE_FUZZY_REFLECTION if fuzzy_reflection else 0)
         p.seed = int(seed) & 0xFFFFFFFF
-        p.flags = (FLAG_COUNTERS if counters else 0) | (FLAG_TREE_KERNEL if tree else 0) | (FLAG_NO_LDS_SCENE if no_lds else 0) | (FLAG_PROFILE if profile else 0) | (FLAG_WAVEFRONT if wavefront else 0) | (FLAG_TILE_KERNEL if tile else 0) | (FLAG_DEVICE_SAMPLES if samples_ptr else 0) | (FLAG_PACKET_WALK if packet else 0)
+        p.flags = (FLAG_COUNTERS if counters else 0) | (FLAG_TREE_KERNEL if tree else 0) | (FLAG_NO_LDS_SCENE if no_lds else 0) | (FLAG_PROFILE if profile else 0) | (FLAG_WAVEFRONT if wavefront else 0) | (FLAG_TILE_KERNEL if tile else 0) | (FLAG_DEVICE_SAMPLES if samples_ptr else 0) | (FLAG_PACKET_WALK if packet else 0) | (FLAG_PRIVATE_WALK if private_walk else 0)
         return p
 
     def render(self, cam, max_depth=4, accel=ACCEL_BVH, spp=0, samples=None, rank=0, world=1, row_block=16,
-               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, packet=False):
+               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, packet=False, private_walk=False):
         """Render into host numpy arrays (rows: res_y for world==1, local_rows otherwise)."""
         rows = cam.res_y if world == 1 else local_rows(cam.res_y, row_block, world)
         rgb8 = np.zeros((rows, cam.res_x, 3), np.uint8)
@@ -389,7 +390,7 @@ class DeviceScene:
         hid = np.full((rows, cam.res_x), -2, np.int32) if want_hit else None
         if samples is not None:
             samples = np.ascontiguousarray(samples, np.float32)
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, 0, packet)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, 0, packet, private_walk)
         o = Outputs(rgb8.ctypes.data, f32.ctypes.data if want_f32 else None,
                     hid.ctypes.data if want_hit else None, 0)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
@@ -399,10 +400,10 @@ class DeviceScene:
         return out
 
     def render_device(self, cam, rgb8_ptr=0, rgb32f_ptr=0, hit_ptr=0, max_depth=4, accel=ACCEL_BVH, spp=0,
-                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False):
+                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False, private_walk=False):
         """Enqueue one frame into caller-owned DEVICE buffers (raw pointers); asynchronous.  samples_ptr: the
         spp > 0 sample array as a device pointer (uploaded once by the caller) instead of `samples`."""
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, samples_ptr, packet)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, samples_ptr, packet, private_walk)
         o = Outputs(rgb8_ptr or None, rgb32f_ptr or None, hit_ptr or None, 1)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
 

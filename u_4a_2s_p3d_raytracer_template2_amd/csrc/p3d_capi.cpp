@@ -157,15 +157,16 @@ struct p3d_scene {
     RawBuf tile_ws, tile_ctrl;
     // "heaviest tile first" for scenes read from HBM: per-tile durations written by the tile kernel, and the order made of
     // them after the first frame of a configuration and every kTileOrderPeriod frames from then on (all on the frame's stream)
-    struct {
+    struct TileOrder {
         RawBuf cost, sorted, iota, order, temp;
         size_t temp_bytes = 0;
-        int32_t key[8] = {0, 0, 0, -1, -1, 0, 0, 0};
+        int32_t key[9] = {0, 0, 0, -1, -1, 0, 0, 0, 0};
         bool valid = false;          // `order` holds an order for `key`
         int frames = 0;              // frames rendered since it was made
-    } tile_lpt;
+        void release() { cost.release(); sorted.release(); iota.release(); order.release(); temp.release(); }
+    } tile_lpt, wave_lpt;            // 16x16 tiles of the tile schedule / 16x4 wave tiles of the tree and wavefront level-1 launches
     bool tile_lpt_enabled = true;
-    struct { uint32_t key = 0xFFFFFFFFu; size_t lds = 0; int blocks = 0; } tile_occ;   // cached occupancy query
+    struct { uint32_t key = 0xFFFFFFFFu; size_t lds = 0; int blocks = 0; } tile_occ[2];   // cached occupancy queries (private / shared walk)
     struct { uint32_t key = 0xFFFFFFFFu; uint32_t stack = 0; unsigned waves = 0, primary_waves = 0; } wf_occ;                 // ... of the deeper-level kernel
     hipStream_t lane_stream[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
@@ -186,7 +187,7 @@ struct p3d_scene {
     // use the fastest one.  All produce identical bits, so the choice is invisible in the output.
     struct SchedulePick {
         int32_t key[8] = {0, 0, 0, -1, -1, 0, 0, 0};
-        float ms[3] = {-1.0f, -1.0f, -1.0f};     // wavefront, tree, tile
+        float ms[6] = {-1.0f, -1.0f, -1.0f, -1.0f, -1.0f, -1.0f};     // wavefront, tree, tile with shared walks; the same with private walks
         int pending = -1, step = 0, best = 2;
     } pick;
     hipEvent_t ev_pick[2] = {nullptr, nullptr};
@@ -416,7 +417,7 @@ int p3d_scene_destroy(p3d_scene* s) {
     s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release(); s->ray_tab.release();
     for (auto& w : s->ws) w.release();
     s->wf_planes.release(); s->tile_ws.release(); s->tile_ctrl.release();
-    s->tile_lpt.cost.release(); s->tile_lpt.sorted.release(); s->tile_lpt.iota.release(); s->tile_lpt.order.release(); s->tile_lpt.temp.release();
+    s->tile_lpt.release(); s->wave_lpt.release();
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     for (int i = 1; i < kLanes; i++) {
         if (s->ev_join[i]) (void)hipEventDestroy(s->ev_join[i]);
@@ -587,6 +588,42 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
 
 }  // namespace
 
+namespace {
+constexpr int kTileOrderPeriod = 64;
+// Before a launch that draws its tiles through an order: buffers for this configuration, the order to use (nullptr until a
+// frame has measured the tiles) and whether this frame's measurements should be sorted into a new order afterwards.
+int tile_order_begin(p3d_scene* s, p3d_scene::TileOrder& L, const int32_t (&key)[9], uint32_t n_tiles, const uint32_t** order,
+                     uint32_t** cost, bool* sort_after) {
+    *order = nullptr; *cost = nullptr; *sort_after = false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s->stream, &cap);
+    if (memcmp(key, L.key, sizeof key) != 0) {
+        L.valid = false;
+        if (cap != hipStreamCaptureStatusNone) { L.key[3] = -1; return P3D_OK; }      // (allocations: not while a capture is open)
+        const size_t nb = (size_t)n_tiles * sizeof(uint32_t);
+        HIP_TRY(L.cost.ensure(nb)); HIP_TRY(L.sorted.ensure(nb)); HIP_TRY(L.iota.ensure(nb)); HIP_TRY(L.order.ensure(nb));
+        size_t tb = 0;
+        HIP_TRY(sort_tiles_by_cost(nullptr, nullptr, nullptr, nullptr, n_tiles, nullptr, tb, s->stream));
+        HIP_TRY(L.temp.ensure(tb)); L.temp_bytes = tb;
+        HIP_TRY(launch_clear_words((uint32_t*)L.cost.p, n_tiles, s->stream));
+        memcpy(L.key, key, sizeof key); L.frames = 0;
+    }
+    *cost = (uint32_t*)L.cost.p;
+    *order = L.valid ? (const uint32_t*)L.order.p : nullptr;
+    *sort_after = cap == hipStreamCaptureStatusNone && (!L.valid || L.frames >= kTileOrderPeriod);
+    return P3D_OK;
+}
+int tile_order_end(p3d_scene* s, p3d_scene::TileOrder& L, uint32_t n_tiles, bool sort_after) {
+    L.frames++;
+    if (sort_after) {            // the order the NEXT frames draw their tiles in, from what this one measured
+        HIP_TRY(sort_tiles_by_cost((const uint32_t*)L.cost.p, (uint32_t*)L.sorted.p, (uint32_t*)L.iota.p, (uint32_t*)L.order.p, n_tiles,
+                                   L.temp.p, L.temp_bytes, s->stream));
+        L.valid = true; L.frames = 0;
+    }
+    return P3D_OK;
+}
+}  // namespace
+
 int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm, const p3d_outputs* out) {
     if (!s || !cam || !prm || !out) return fail(P3D_ERR_ARG, "NULL argument");
     if (cam->res_x <= 0 || cam->res_y <= 0) return fail(P3D_ERR_ARG, "bad resolution");
@@ -619,9 +656,12 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     //  0.133 vs 0.137 ms; P3D_FLAG_PACKET_WALK asks for the wave-wide walk, which exists for trees up to 64 node pairs)
     const bool packet = prm->accel != P3D_ACCEL_GRID && (prm->flags & P3D_FLAG_PACKET_WALK) &&
                         s->stats.n_nodes <= s->packet_node_limit;
-    // scenes read from HBM: the lanes of a wave share their walks (p3d_traverse.h: closest_hit_shared), unless switched off
-    const bool shared_walk = !lds_scene && prm->accel != P3D_ACCEL_GRID && !packet && s->share_min_idle > 0 && s->share_min_idle <= 64;
-    const int walk = prm->accel == P3D_ACCEL_GRID ? 2 : (packet ? 1 : (shared_walk ? 3 : 0));
+    // scenes read from HBM: the lanes of a wave can share their walks (p3d_traverse.h: closest_hit_shared).  Whether they do
+    // is part of the measured choice below (it pays on some scenes and costs on others); P3D_FLAG_PRIVATE_WALK rules it out.
+    const bool can_share = !lds_scene && prm->accel != P3D_ACCEL_GRID && !packet && s->share_min_idle > 0 && s->share_min_idle <= 64 &&
+                           !(prm->flags & P3D_FLAG_PRIVATE_WALK);
+    bool shared_walk = can_share;
+    int walk = prm->accel == P3D_ACCEL_GRID ? 2 : (packet ? 1 : (shared_walk ? 3 : 0));
     if (prm->accel == P3D_ACCEL_GRID) {
         if (s->unit_rays_only) return fail(P3D_ERR_STATE, "scene was built with cull_never_hit: GRID mode walks the reference's grid over ALL primitives; use accel BVH");
         if (!s->grid_ready) {
@@ -750,20 +790,33 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     // register budget of the tile kernel: scenes read from HBM run it at 5 waves per SIMD (with the work-sharing walk the
     // default allocation is 129 VGPRs: one over the step to 3 waves per SIMD, i.e. 3 workgroups per CU instead of 4)
     const int tile_occ = s->occupancy ? s->occupancy : (lds_scene ? 0 : 5);
-    bool tile_ok = tile_kernel_lds_bytes(PT, lds_scene) <= kMaxLdsBytes && D <= 16;
-    if (tile_ok) {
+    bool tile_ok = false;
+    auto tile_query = [&]() -> int {                      // what the tile schedule can have with the walk in force
+        tile_blocks = 0;
+        tile_ok = tile_kernel_lds_bytes(PT, lds_scene) <= kMaxLdsBytes && D <= 16;
+        if (!tile_ok) return P3D_OK;
         const uint32_t okey = (count ? 1u : 0u) | (lds_scene ? 2u : 0u) | ((uint32_t)walk << 2) | (stochastic ? 16u : 0u) | ((uint32_t)tile_occ << 5);
         const size_t olds = tile_kernel_lds_bytes(PT, lds_scene);
-        if (s->tile_occ.key != okey || s->tile_occ.lds != olds) {
-            HIP_TRY(tile_kernel_resident_blocks(PT, count, lds_scene, walk, tile_occ, &s->tile_occ.blocks));
-            s->tile_occ.key = okey; s->tile_occ.lds = olds;
+        auto* slot = &s->tile_occ[walk == 3 ? 1 : 0];
+        if (slot->key != okey || slot->lds != olds) {
+            HIP_TRY(tile_kernel_resident_blocks(PT, count, lds_scene, walk, tile_occ, &slot->blocks));
+            slot->key = okey; slot->lds = olds;
         }
-        tile_blocks = s->tile_occ.blocks;
-        tile_blocks = std::min(tile_blocks, PT.n_tiles);
+        tile_blocks = std::min(slot->blocks, PT.n_tiles);
         tile_blocks = (int)std::min<size_t>((size_t)tile_blocks, budget / slot_bytes);
         // fewer resident workgroups than a quarter of the CUs: the per-tile worst case of this depth does not fit
         tile_ok = tile_blocks >= std::min(64, PT.n_tiles);
-    }
+        return P3D_OK;
+    };
+    auto apply_walk = [&](bool share) -> int {            // private <-> shared walks for this frame (scenes read from HBM)
+        if (share == shared_walk) return P3D_OK;
+        shared_walk = share;
+        walk = shared_walk ? 3 : 0;
+        P.trav_stack_dwords = P.trav_stack_entries * kHbmStackDwordsPerEntry + (shared_walk ? kShareDwords : 0u);
+        PT.trav_stack_dwords = P.trav_stack_dwords;
+        return tile_query();
+    };
+    { int rc = tile_query(); if (rc) return rc; }
     // wavefront bands: worst-case queues for a band of tile rows must fit the workspace budget
     const size_t tile_row_px = (size_t)P.tiles_x * 64 * P.wg_waves;
     // sample passes of one frame run on up to kLanes streams, each with its share of the budget
@@ -780,6 +833,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
 
     int sched = SCHED_TILE;
     int measuring = -1;                 // schedule this frame is timed as, for the pick below
+    int measured_cand = -1;             // ... and the pick's candidate (schedule x shared / private walks) it counts for
     if (prm->flags & P3D_FLAG_TREE_KERNEL) sched = SCHED_TREE;
     else if (prm->flags & P3D_FLAG_WAVEFRONT) sched = SCHED_WAVEFRONT;
     else if (prm->flags & P3D_FLAG_TILE_KERNEL) sched = SCHED_TILE;
@@ -795,20 +849,25 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         // random primitives: wavefront 3.7, tile 6.1, tree 9.5), so the library MEASURES: the first frames of a
         // configuration run every available schedule twice -- the first time untimed: code-object load,
         // workspace allocation -- and the fastest one stays.  All produce identical bits.
+        // Scenes whose lanes can share their walks measure every schedule both ways (candidates 0-2 shared, 3-5 private).
         constexpr int NS = 3;
-        const bool avail[NS] = {wavefront_ok, !stochastic, tile_ok};
+        const int NC = can_share ? 2 * NS : NS;
+        const bool avail_s[NS] = {wavefront_ok, !stochastic, tile_ok};
+        auto cand_share = [&](int c) { return can_share && c < NS; };
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(s->stream, &cap);
         p3d_scene::SchedulePick& pk = s->pick;
         const int32_t key[8] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world,
-                                (int32_t)((prm->flags & (P3D_FLAG_NO_LDS_SCENE | P3D_FLAG_PACKET_WALK | P3D_FLAG_COUNTERS)) | (prm->features << 8))};
+                                (int32_t)((prm->flags & (P3D_FLAG_NO_LDS_SCENE | P3D_FLAG_PACKET_WALK | P3D_FLAG_COUNTERS | P3D_FLAG_PRIVATE_WALK)) | (prm->features << 9))};
+        int cand = -1;
         if (cap != hipStreamCaptureStatusNone) {
             // events cannot be read while the stream is being captured: use what is known, measure nothing
-            if (memcmp(key, pk.key, sizeof key) == 0 && pk.step >= 2 * NS) sched = pk.best;
+            if (memcmp(key, pk.key, sizeof key) == 0 && pk.step >= 2 * NC) cand = pk.best;
         } else {
             if (memcmp(key, pk.key, sizeof key) != 0) {
                 memcpy(pk.key, key, sizeof key);
-                pk.ms[0] = pk.ms[1] = pk.ms[2] = -1.0f; pk.pending = -1; pk.step = 0; pk.best = SCHED_TILE;
+                for (float& m : pk.ms) m = -1.0f;
+                pk.pending = -1; pk.step = 0; pk.best = SCHED_TILE;
             }
             if (pk.pending >= 0) {              // collect the measurement of the previous frame
                 HIP_TRY(hipEventSynchronize(s->ev_pick[1]));
@@ -817,22 +876,32 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
                 if (pk.ms[pk.pending] < 0.0f || ms < pk.ms[pk.pending]) pk.ms[pk.pending] = ms;
                 pk.pending = -1;
             }
-            while (pk.step < 2 * NS && !avail[pk.step / 2]) pk.step = (pk.step / 2 + 1) * 2;     // skip what cannot run
-            if (pk.step < 2 * NS) {
-                sched = pk.step / 2;
-                if (pk.step & 1) measuring = sched;
+            while (pk.step < 2 * NC && !avail_s[(pk.step / 2) % NS]) pk.step = (pk.step / 2 + 1) * 2;     // skip what cannot run
+            if (pk.step < 2 * NC) {
+                cand = pk.step / 2;
+                if (pk.step & 1) measuring = cand;
                 pk.step++;
             } else {
-                if (pk.step == 2 * NS) {
+                if (pk.step == 2 * NC) {
                     pk.best = -1;
-                    for (int k = 0; k < NS; k++)
-                        if (avail[k] && pk.ms[k] >= 0.0f && (pk.best < 0 || pk.ms[k] < pk.ms[pk.best])) pk.best = k;
+                    for (int k = 0; k < NC; k++)
+                        if (avail_s[k % NS] && pk.ms[k] >= 0.0f && (pk.best < 0 || pk.ms[k] < pk.ms[pk.best])) pk.best = k;
                     if (pk.best < 0) pk.best = tile_ok ? SCHED_TILE : (wavefront_ok ? SCHED_WAVEFRONT : SCHED_TREE);
                     pk.step++;
+                    if (s->verbose)
+                        fprintf(stderr, "p3d: measured choice (ms; wavefront / tree / tile, shared walks then private): %.3f %.3f %.3f | %.3f %.3f %.3f -> %d\n",
+                                pk.ms[0], pk.ms[1], pk.ms[2], pk.ms[3], pk.ms[4], pk.ms[5], pk.best);
                 }
-                sched = pk.best;
+                cand = pk.best;
             }
         }
+        if (cand >= 0) {
+            sched = cand % NS;
+            int rc = apply_walk(cand_share(cand));
+            if (rc) return rc;
+        }
+        measured_cand = measuring;
+        if (measuring >= 0) measuring = measuring % NS;
     }
     // a schedule whose workspace does not fit falls back: tile -> wavefront (bands) -> tree
     if (sched == SCHED_TILE && !tile_ok) sched = wavefront_ok ? SCHED_WAVEFRONT : SCHED_TREE;
@@ -888,52 +957,31 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
         // heaviest tile first (scenes read from HBM: their tiles differ by orders of magnitude; LDS scenes' do not)
         bool lpt_sort = false;
+        const int32_t lkey[9] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world, (int32_t)prm->features, SCHED_TILE};
         if (!lds_scene && s->tile_lpt_enabled && PT.n_tiles >= 64) {
-            auto& L = s->tile_lpt;
-            const int32_t lkey[8] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world, (int32_t)prm->features};
-            hipStreamCaptureStatus lcap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(s->stream, &lcap);
-            if (memcmp(lkey, L.key, sizeof lkey) != 0) {
-                if (lcap == hipStreamCaptureStatusNone) {          // (allocations: not while a capture is open)
-                    const size_t nb = (size_t)PT.n_tiles * sizeof(uint32_t);
-                    HIP_TRY(L.cost.ensure(nb)); HIP_TRY(L.sorted.ensure(nb)); HIP_TRY(L.iota.ensure(nb)); HIP_TRY(L.order.ensure(nb));
-                    size_t tb = 0;
-                    HIP_TRY(sort_tiles_by_cost(nullptr, nullptr, nullptr, nullptr, (uint32_t)PT.n_tiles, nullptr, tb, s->stream));
-                    HIP_TRY(L.temp.ensure(tb)); L.temp_bytes = tb;
-                    HIP_TRY(launch_clear_words((uint32_t*)L.cost.p, (uint32_t)PT.n_tiles, s->stream));
-                    memcpy(L.key, lkey, sizeof lkey); L.valid = false; L.frames = 0;
-                } else {
-                    L.valid = false; L.key[3] = -1;
-                }
-            }
-            if (memcmp(lkey, L.key, sizeof lkey) == 0) {
-                PT.tile_cost = (uint32_t*)L.cost.p;
-                PT.tile_order = L.valid ? (const uint32_t*)L.order.p : nullptr;
-                constexpr int kTileOrderPeriod = 64;
-                lpt_sort = lcap == hipStreamCaptureStatusNone && (!L.valid || L.frames >= kTileOrderPeriod);
-            }
+            int rc = tile_order_begin(s, s->tile_lpt, lkey, (uint32_t)PT.n_tiles, &PT.tile_order, &PT.tile_cost, &lpt_sort);
+            if (rc) return rc;
         }
         if (s->verbose)
             fprintf(stderr, "p3d: tile schedule: %d workgroups (occupancy query: %d on the device), %zu B LDS each, %zu B workspace slot, %d tiles\n",
-                    tile_blocks, s->tile_occ.blocks, tile_kernel_lds_bytes(PT, lds_scene), slot_bytes, PT.n_tiles);
+                    tile_blocks, s->tile_occ[walk == 3 ? 1 : 0].blocks, tile_kernel_lds_bytes(PT, lds_scene), slot_bytes, PT.n_tiles);
         HIP_TRY(launch_wf_tile(PT, count, lds_scene, walk, tile_occ, (unsigned)tile_blocks, s->stream));
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream));
-        if (PT.tile_cost) {
-            auto& L = s->tile_lpt;
-            L.frames++;
-            if (lpt_sort) {          // the order the NEXT frames draw their tiles in, from what this one measured
-                HIP_TRY(sort_tiles_by_cost((const uint32_t*)L.cost.p, (uint32_t*)L.sorted.p, (uint32_t*)L.iota.p, (uint32_t*)L.order.p,
-                                           (uint32_t)PT.n_tiles, L.temp.p, L.temp_bytes, s->stream));
-                L.valid = true; L.frames = 0;
-            }
-        }
+        if (PT.tile_cost) { int rc = tile_order_end(s, s->tile_lpt, (uint32_t)PT.n_tiles, lpt_sort); if (rc) return rc; }
     } else if (use_tree) {
         if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));
         P.wf_tile_row0 = 0; P.wf_tile_rows = P.tiles_y;
+        bool lpt_sort = false;
+        const int32_t lkey[9] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world, (int32_t)prm->features, SCHED_TREE};
+        if (!lds_scene && s->tile_lpt_enabled && P.n_tiles >= 64 && P.xcd_chunk == 1) {
+            int rc = tile_order_begin(s, s->wave_lpt, lkey, (uint32_t)P.n_tiles, &P.tile_order, &P.tile_cost, &lpt_sort);
+            if (rc) return rc;
+        }
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
         // scenes read from HBM: a register budget of 6 waves per SIMD (dragon with the flat walk loop: 1.285 ms at 5, 1.239 at 6)
         HIP_TRY(launch_tree(P, count, lds_scene, s->occupancy ? s->occupancy : (lds_scene ? 0 : 6), shared_walk, s->stream));
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], s->stream));
+        if (P.tile_cost) { int rc = tile_order_end(s, s->wave_lpt, (uint32_t)P.n_tiles, lpt_sort); if (rc) return rc; }
     } else {
         // a shard owns every kShards-th tile of the band
         const size_t band_tiles = band_tile_rows * (size_t)P.tiles_x;
@@ -958,6 +1006,13 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         if (prm->spp > 0) {
             HIP_TRY(s->wf_planes.ensure((size_t)P.wf_nsamples * npx * 12));
             P.wf_planes = (float*)s->wf_planes.p; P.wf_plane_stride = (uint64_t)npx * 3;
+        }
+        bool lpt_sort = false;
+        const int32_t lkey[9] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world, (int32_t)prm->features, SCHED_WAVEFRONT};
+        if (!lds_scene && s->tile_lpt_enabled && P.n_tiles >= 64 && P.xcd_chunk == 1 && lanes == 1 && band_tile_rows >= (size_t)P.tiles_y) {
+            // (whole-frame passes only: a band numbers its tiles from its own first row)
+            int rc = tile_order_begin(s, s->wave_lpt, lkey, (uint32_t)P.n_tiles, &P.tile_order, &P.tile_cost, &lpt_sort);
+            if (rc) return rc;
         }
         if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));   // after the (host-side) allocations
         if (lanes > 1) {                                   // the other lanes start after what the stream holds
@@ -988,13 +1043,14 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         }
         // a pixel's clamped sample colours are summed in sample order, then divided by 16
         if (prm->spp > 0) HIP_TRY(launch_sum_samples(P, 0, npx, s->stream));
+        if (P.tile_cost) { int rc = tile_order_end(s, s->wave_lpt, (uint32_t)P.n_tiles, lpt_sort); if (rc) return rc; }
     }
     if (profile) { HIP_TRY(hipEventRecord(s->ev_prof[1], s->stream)); s->profile_valid = true; }
     if (measuring >= 0) {
         HIP_TRY(hipEventRecord(s->ev_pick[1], s->stream));
         // a frame pushed onto another schedule by the workspace budget says the measured one is not available
-        if (sched == measuring) s->pick.pending = sched;
-        else s->pick.ms[measuring] = 3.0e38f;
+        if (sched == measuring) s->pick.pending = measured_cand;
+        else s->pick.ms[measured_cand] = 3.0e38f;
     }
     if (out->memory != 1) {
         // host planes hold res_y rows for a whole frame, p3d_local_rows() rows for a shard

@@ -96,10 +96,14 @@ __device__ __forceinline__ bool tile_pixel(const LaunchParams& P, int& x, int& y
     // larger chunks trade balance for L2 locality on scenes whose BVH does not fit one L2.
     const int bid = vbid >= 0 ? vbid : (int)blockIdx.x;      // (vbid: a workgroup that handles several tiles numbers them itself)
     const int j = bid >> 3;
-    const int tile = ((j / P.xcd_chunk) * 8 + (bid & 7)) * P.xcd_chunk + (j % P.xcd_chunk);
+    int tile = ((j / P.xcd_chunk) * 8 + (bid & 7)) * P.xcd_chunk + (j % P.xcd_chunk);
     x = 0; y = 0; row = 0;
     if (tile_out) *tile_out = tile;
     if (tile >= P.n_tiles) return false;
+    if (P.tile_order) {                       // heaviest first (scenes read from HBM, once a frame has measured the tiles)
+        tile = (int)P.tile_order[tile];
+        if (tile_out) *tile_out = tile;
+    }
     const int tx = tile % P.tiles_x, ty = P.wf_tile_row0 + tile / P.tiles_x;
     x = tx * 16 + (lane & 15);
     row = ty * (P.wg_waves * 4) + (lane >> 4) + wave * 4;         // row in the compact local buffer
@@ -366,6 +370,7 @@ __global__ __launch_bounds__(LDS ? 1024 : 64) P3D_OCC(OCC) void wf_primary_kerne
         if (__ballot(valid) == 0) continue;
         const Shard sh = shard_of(P, (uint32_t)tile % (uint32_t)P.wf_shards, par);
         const size_t p = (size_t)row * P.res_x + x;
+        const unsigned long long t_tile = P.tile_cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
         stamp(P, tile, 0);
         Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
         if (valid) ray = camera_ray(P, x, y, P.wf_sample);
@@ -381,6 +386,7 @@ __global__ __launch_bounds__(LDS ? 1024 : 64) P3D_OCC(OCC) void wf_primary_kerne
         stamp(P, tile, 3);
         emit(P, sh, 1, valid, (uint32_t)p, 1.0f, o);
         stamp(P, tile, 4);
+        if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
         my_pixels += (valid && P.wf_sample == 0) ? 1u : 0u;
     }
     if (COUNT) flush_counters<COUNT>(P, ctr, my_pixels);
@@ -916,6 +922,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kern
     int x, y, row, tile;
     const bool in_image = tile_pixel(P, x, y, row, &tile);
     if (SHARED ? __ballot(in_image) == 0 : !in_image) return;   // no barriers below: early exit is safe
+    const unsigned long long t_tile = P.tile_cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
     stamp(P, tile, 0);
     uint32_t priv[PRIV > 0 ? PRIV : 1];
     uint32_t* wbase;
@@ -936,6 +943,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kern
             flush_counters<COUNT>(P, ctr, 1u);
         }
         stamp(P, tile, 4);
+        if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
         return;
     }
     if (P.spp == 0) {                                    // RT/main.cpp:756-775
@@ -955,6 +963,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kern
     if (P.hit_id) P.hit_id[p] = hid;
     flush_counters<COUNT>(P, ctr, 1u);
     stamp(P, tile, 4);              // (diagnostic; the wave has reconverged here: its slowest lane is done)
+    if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
 }
 
 // per-column / per-row factors of the pixel-centre camera rays (one launch per resolution)
