@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-3 evidence on the GPU box (run through gpurun from the repo root): self-checking bench lines, rocprofv3 kernel
+# stats and PMC summaries of config 2 (bench.py, one frame in flight), config 3 (dragon 1080p), config 4 (4096^2 d6 spp2)
+# and the 1e6-primitive scaling scene.  Results under gpurun_out/r03/; the summaries worth judging are copied to profiles/.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r03
+mkdir -p $O
+cd $R
+python bench.py > $O/bench_config2.json 2> $O/bench_config2.err; tail -c 300 $O/bench_config2.json; echo
+python bench.py --workload config3 --steps 20 --warmup 3 > $O/bench_config3.json 2> $O/bench_config3.err; tail -c 300 $O/bench_config3.json; echo
+python bench.py --workload config4 --steps 10 --warmup 2 > $O/bench_config4.json 2> $O/bench_config4.err; tail -c 300 $O/bench_config4.json; echo
+python bench.py --workload synthetic --prims 1000000 --steps 10 --warmup 2 > $O/bench_synthetic_1e6.json 2> $O/bench_synthetic_1e6.err; tail -c 300 $O/bench_synthetic_1e6.json; echo
+python bench.py --workload pathtracer --steps 3 --warmup 1 > $O/bench_pathtracer.json 2> $O/bench_pathtracer.err; tail -c 300 $O/bench_pathtracer.json; echo
+cd /tmp && export TMPDIR=/tmp
+kt() {   # kt TAG program args...
+  local tag=$1; shift
+  rocprofv3 --kernel-trace --stats -d $O/kt_$tag --output-format csv -- python3 "$@" > $O/kt_$tag.log 2>&1
+  cp $(ls $O/kt_$tag/*/*kernel_stats.csv | head -1) $O/${tag}_kernel_stats.csv
+}
+pmc() {  # pmc TAG script args...
+  local tag=$1; shift
+  local script=$1; shift
+  (cd $R && P3D_PMC_SCRIPT=$script P3D_PMC_PASSES="${P3D_PMC_PASSES:-1 2 3 4 5 6}" tools/pmc_collect.sh r03_$tag "$@" > $O/pmc_$tag.log 2>&1)
+  cp $R/gpurun_out/pmc_r03_$tag/summary.json $O/${tag}_pmc.json
+}
+kt config2 $R/bench.py --no-cpu-baseline --frames-in-flight 1 --steps 10 --warmup 3
+kt config2_default $R/bench.py --no-cpu-baseline
+pmc config2 bench.py --no-cpu-baseline --frames-in-flight 1 --steps 2 --warmup 2
+kt config3 $R/tools/render_frames.py dragon default 40
+pmc config3 tools/render_frames.py dragon default 30
+kt config4 $R/tools/config4.py
+pmc config4 tools/config4.py
+kt synthetic_1000000 $R/tools/render_frames.py 1000000 default 30
+pmc synthetic_1000000 tools/render_frames.py 1000000 default 24
+ls -la $O | head -60
+echo done

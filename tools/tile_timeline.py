@@ -29,7 +29,7 @@ else:
     cam = hs.camera()
     ds = P.DeviceScene.from_host(hs)
 buf = torch.zeros((H + 16, W, 3), dtype=torch.uint8, device="cuda")
-ntiles = 120 * 68
+ntiles = 120 * 68 * 4
 st = torch.zeros((ntiles + 64, 8), dtype=torch.int64, device="cuda")
 for _ in range(3):
     ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=depth, tile=True)

@@ -199,14 +199,11 @@ struct p3d_scene {
     int resolve_blocks_per_shard = 16;   // a resolve launch is latency-bound: few nodes per thread, many threads
     int fused_resolve_shard_px = 8192;   // frames with at most this many pixels per shard resolve all levels in one launch
     bool pair_mode = true;               // the last level combines sibling rays with their parent (LaunchParams::wf_pair_in)
-    bool fuse_last = false;              // LDS scenes: level D - 1 traces level D itself (LaunchParams::wf_fuse_last); replaces pair mode
     uint32_t dbg_skip = 0;               // diagnostic builds only (LaunchParams::dbg_skip)
     unsigned long long* dbg_stamps = nullptr; int dbg_stamp_level = 1;
     int occupancy = 0;     // 0 = compiler default register budget, else 5 / 6 / 8 waves per SIMD
     uint32_t tri_quads = 3;    // 16-byte quads per triangle test record (3; 4 = round 2's 64-byte stride, P3D_TRI_STRIDE=64)
     bool verbose = false;      // P3D_VERBOSE=1: launch geometry on stderr (diagnostic)
-    int primary_tiles_per_wg = 1;   // tiles a workgroup of that launch handles one after the other
-    int primary_wg_waves = 4;  // waves per workgroup of the level-1 launch of LDS scenes (wavefront schedule, whole-frame passes)
     int share_min_idle = 16;   // work-sharing walk of scenes read from HBM: idle lanes before a steal round (0 or > 64: private walks)
 };
 
@@ -318,12 +315,9 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     if (const char* e = getenv("P3D_FUSED_RESOLVE_PX")) { int v = atoi(e); if (v >= 0 && v <= (1 << 24)) s->fused_resolve_shard_px = v; }
     s->pair_mode = getenv("P3D_NO_PAIR_MODE") == nullptr;
     s->verbose = getenv("P3D_VERBOSE") != nullptr;
-    if (const char* e = getenv("P3D_FUSE_LAST")) s->fuse_last = atoi(e) != 0;
     if (const char* e = getenv("P3D_TILE_LPT")) s->tile_lpt_enabled = atoi(e) != 0;
     if (const char* e = getenv("P3D_OCC")) { int v = atoi(e); if (v == 0 || v == 5 || v == 6) s->occupancy = v; }
     if (const char* e = getenv("P3D_TRI_STRIDE")) s->tri_quads = atoi(e) == 64 ? 4u : 3u;
-    if (const char* e = getenv("P3D_PRIMARY_TILES")) { int v = atoi(e); if (v >= 1 && v <= 8) s->primary_tiles_per_wg = v; }
-    if (const char* e = getenv("P3D_PRIMARY_WG_WAVES")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) s->primary_wg_waves = v; }
     if (const char* e = getenv("P3D_SHARE_MIN_IDLE")) { int v = atoi(e); if (v >= 0 && v <= 65) s->share_min_idle = v; }
     if (const char* e = getenv("P3D_DEBUG_SKIP")) s->dbg_skip = (uint32_t)atoi(e);      // read by -DP3D_DEBUG_SKIP builds only
     auto bail = [&](hipError_t e, const char* what) {
@@ -516,41 +510,14 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
     const unsigned resident_waves = s->wf_occ.waves;
     // pair mode (LaunchParams::wf_pair_in): the last level combines sibling rays with their parent in registers, so
     // level D - 1 needs no resolve launch
-    // fused last level (LaunchParams::wf_fuse_last): the launch of level D - 1 traces level D itself; takes the place of pair mode
-    const bool fuse_last = D >= 2 && s->fuse_last && lds;
-    const bool pair_mode = D >= 2 && s->pair_mode && !fuse_last;
-    const int last_launch = fuse_last ? D - 1 : D;               // deepest level that gets a launch of its own
-    P.wf_fuse_last = (fuse_last && D == 2) ? 1 : 0;
+    const bool pair_mode = D >= 2 && s->pair_mode;
     P.wf_pair_in = 0; P.wf_pair_out = (pair_mode && D == 2) ? 1 : 0;
     P.wf_nodes_grand = nullptr; P.wf_ncap_grand = 0;
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], stream));
-    {
-        // level 1 of an LDS scene: bigger workgroups (fewer to hand out, one scene copy for more waves) when the pass is
-        // the whole frame.  Only the tile geometry of THIS launch changes: a ray's shard is still its tile's number % shards,
-        // and shard_px (the caller's) already covers the larger tiles.
-        LaunchParams P1 = P;
-        const int w1 = s->primary_wg_waves;
-        if (lds && w1 != P.wg_waves && P.wf_tile_row0 == 0 && P.wf_tile_rows == P.tiles_y) {
-            P1.wg_waves = w1;
-            P1.tiles_y = (P.local_rows + 4 * w1 - 1) / (4 * w1);
-            P1.n_tiles = P1.tiles_x * P1.tiles_y;
-            P1.wf_tile_rows = P1.tiles_y;
-            const int chunks = (P1.n_tiles + P1.xcd_chunk - 1) / P1.xcd_chunk;
-            P1.grid_blocks = ((chunks + 7) / 8) * 8 * P1.xcd_chunk;
-        }
-        P1.wf_tiles_per_wg = 1;
-        if (lds && s->primary_tiles_per_wg > 1) {
-            // ... and / or several tiles per workgroup, the grid shrunk accordingly (whole multiples of 8 workgroups)
-            P1.wf_tiles_per_wg = s->primary_tiles_per_wg;
-            const int per = (P1.grid_blocks + P1.wf_tiles_per_wg - 1) / P1.wf_tiles_per_wg;
-            P1.grid_blocks = ((per + 7) / 8) * 8;
-        }
-        HIP_TRY(launch_wf_primary(P1, count, lds, walk, occ, stream));
-    }
+    HIP_TRY(launch_wf_primary(P, count, lds, walk, occ, stream));
     if (profile) HIP_TRY(hipEventRecord(s->ev_prof[3], stream));
-    for (int l = 2; l <= last_launch; l++) {
+    for (int l = 2; l <= D; l++) {
         P.wf_level = l;
-        P.wf_fuse_last = (fuse_last && l == D - 1) ? 1 : 0;
         P.wf_rays_in = rays(l); P.wf_count_in = qcount(l); P.wf_cap_in = cap(l);
         P.wf_rays_out = rays(l + 1); P.wf_count_out = qcount(l + 1); P.wf_cap_out = cap(l + 1);
         P.wf_rng_in = rng(l); P.wf_rng_out = rng(l + 1);
@@ -565,8 +532,8 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
         waves = std::max<unsigned>(kShards * 4, (waves / (kShards * 4)) * (kShards * 4));   // whole workgroups per shard
         HIP_TRY(launch_wf_secondary(P, count, lds, walk, occ, waves, stream));
     }
-    P.wf_pair_in = P.wf_pair_out = 0; P.wf_fuse_last = 0;
-    const int top = (pair_mode || fuse_last) ? D - 2 : D - 1;            // highest level that still has to be resolved by a launch
+    P.wf_pair_in = P.wf_pair_out = 0;
+    const int top = pair_mode ? D - 2 : D - 1;            // highest level that still has to be resolved by a launch
     if (top >= 2 && shard_px <= (size_t)s->fused_resolve_shard_px) {
         // small frame (a rank's share of a tiled frame): all resolve levels in ONE launch, a workgroup per shard
         ResolveLevels R;
@@ -985,12 +952,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     } else {
         // a shard owns every kShards-th tile of the band
         const size_t band_tiles = band_tile_rows * (size_t)P.tiles_x;
-        size_t shard_px = ((band_tiles + kShards - 1) / kShards) * 64 * P.wg_waves;
-        if (lds_scene && s->primary_wg_waves > P.wg_waves) {      // level 1 may run with larger tiles (run_wavefront_pass)
-            const size_t rows1 = 4 * (size_t)s->primary_wg_waves;
-            const size_t tiles1 = (size_t)P.tiles_x * (((size_t)P.local_rows + rows1 - 1) / rows1);
-            shard_px = std::max(shard_px, ((tiles1 + kShards - 1) / kShards) * 64 * (size_t)s->primary_wg_waves);
-        }
+        const size_t shard_px = ((band_tiles + kShards - 1) / kShards) * 64 * P.wg_waves;
         for (int ln = 0; ln < lanes; ln++) {
             p3d_scene::Workspace& w = s->ws[ln];
             for (int l = 2; l <= D; l++) HIP_TRY(w.rays[l].ensure((shard_px << (l - 1)) * kShards * sizeof(RayRec)));

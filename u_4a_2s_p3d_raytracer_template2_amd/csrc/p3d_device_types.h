@@ -122,7 +122,6 @@ struct LaunchParams {
     int32_t wf_level;              // tree level this launch traces / resolves (1 = primary rays)
     int32_t wf_sample, wf_nsamples;
     int32_t wf_tile_row0, wf_tile_rows;      // band of 16x4-tile rows handled by this pass
-    int32_t wf_tiles_per_wg;                 // level-1 launch: tiles a workgroup handles one after the other (>= 1)
     // The queues are split into wf_shards independent shards (tile t -> shard t % wf_shards; a
     // ray stays in its pixel's shard for its whole tree) so that the per-wave slot allocation
     // atomics spread over wf_shards counters instead of serialising on one word.  Pointers below
@@ -145,7 +144,6 @@ struct LaunchParams {
     // rays all return at once, RT/main.cpp:632-634 -- combines each pair with its parent's parked record in registers and
     // hands the result to the GRANDPARENT (level D - 2 nodes, or the pixel): no resolve launch for level D - 1.
     int32_t wf_pair_in, wf_pair_out;
-    int32_t wf_fuse_last;             // this launch is level D - 1 and traces its nodes' children (level D) itself: fuse_last_level()
     NodeRec* wf_nodes_grand; uint32_t wf_ncap_grand;
     NodeRec* wf_nodes_self;    uint32_t* wf_ncount_self;         // level wf_level nodes
     float* wf_planes; uint64_t wf_plane_stride;                   // [sample][local px][3] clamped sample colours; floats per plane

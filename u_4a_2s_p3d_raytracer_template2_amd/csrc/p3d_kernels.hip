@@ -88,19 +88,20 @@ __global__ __launch_bounds__(256) void sum_samples_kernel(const LaunchParams P, 
 }
 
 // tile -> pixel.  Returns false for lanes outside the image.
-__device__ __forceinline__ bool tile_pixel(const LaunchParams& P, int& x, int& y, int& row, int* tile_out = nullptr, int vbid = -1) {
+template <bool ORDERED = false>
+__device__ __forceinline__ bool tile_pixel(const LaunchParams& P, int& x, int& y, int& row, int* tile_out = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // XCD-aware tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
     // share one, each XCD has its own L2), so XCD k is given CHUNKS of xcd_chunk consecutive
     // tiles: chunk c goes to XCD c % 8.  xcd_chunk = 1 is the identity map (best load balance),
     // larger chunks trade balance for L2 locality on scenes whose BVH does not fit one L2.
-    const int bid = vbid >= 0 ? vbid : (int)blockIdx.x;      // (vbid: a workgroup that handles several tiles numbers them itself)
+    const int bid = blockIdx.x;
     const int j = bid >> 3;
     int tile = ((j / P.xcd_chunk) * 8 + (bid & 7)) * P.xcd_chunk + (j % P.xcd_chunk);
     x = 0; y = 0; row = 0;
     if (tile_out) *tile_out = tile;
     if (tile >= P.n_tiles) return false;
-    if (P.tile_order) {                       // heaviest first (scenes read from HBM, once a frame has measured the tiles)
+    if (ORDERED && P.tile_order) {            // heaviest first (scenes read from HBM, once a frame has measured the tiles)
         tile = (int)P.tile_order[tile];
         if (tile_out) *tile_out = tile;
     }
@@ -267,37 +268,6 @@ __device__ __forceinline__ void combine_pair(const LaunchParams& P, const Shard&
     dst[0] = ret.x; dst[1] = ret.y; dst[2] = ret.z;
 }
 
-// Last level fused into the launch of level D - 1 (LaunchParams::wf_fuse_last): every ray of level D returns at once
-// (RT/main.cpp:632-634), so the lane that shaded a level-(D-1) node traces that node's one or two children ITSELF, right
-// there, and combines them with the node in registers -- "color += reflection_color * KR * specColor + refraction_color *
-// (1 - KR)", RT/main.cpp:719; a child never traced adds zero -- no queue, no parked record, no launch for level D.
-// Must be reached by all lanes of the wave together.  Returns the node as a terminal one.
-template <bool COUNT, int WALK, class SV, bool STOCH>
-__device__ __forceinline__ NodeOut fuse_last_level(const LaunchParams& P, const SV& sv, const NodeOut& o, bool live, int level, float ior_1,
-                                                   const TravCtx& tc, Ctr& ctr) {
-    const bool parent = live && !o.terminal;
-    if (__ballot(parent) == 0) return o;
-    V3 refl_ret = mk(0.0f, 0.0f, 0.0f), refr_ret = refl_ret;
-    _Pragma("clang loop unroll(disable)")
-    for (int c = 0; c < 2; c++) {
-        const bool a = parent && (c == 0 ? o.has_refl : o.has_refr);
-        if (__ballot(a) == 0) continue;
-        Ray cr; cr.o = c == 0 ? o.refl.o : o.refr.o; cr.d = c == 0 ? o.refl.d : o.refr.d;
-        const float cior = c == 0 ? ior_1 : o.newIor;                    // the reflection child keeps ior_1
-        const uint32_t crng = c == 0 ? o.rng_refl : o.rng_refr;
-        const Hit ch = find_closest<COUNT, WALK>(P, sv, cr, a, tc, ctr);
-        const NodeOut co = shade_hit<COUNT, WALK, SV, STOCH>(P, sv, cr, ch, a, level + 1, cior, tc, ctr, crng);
-        if (a) { if (c == 0) refl_ret = co.ret; else refr_ret = co.ret; }
-    }
-    NodeOut t = o;
-    if (parent) {
-        const Mtl M = load_material(sv, o.mat);
-        t.terminal = true;
-        t.ret = combine_node(o.color, o.KR, M.spec, refl_ret, refr_ret);
-    }
-    return t;
-}
-
 // this wave's traversal stack: after the (optional) scene copy, one region per wave
 template <bool LDS>
 __device__ __forceinline__ TravCtx wave_stack(const LaunchParams& P, uint32_t extra_dwords_per_wave, uint32_t** wave_base = nullptr) {
@@ -325,8 +295,14 @@ __device__ __forceinline__ void stamp(const LaunchParams& P, int tile, int k) {
 // the same for the deeper-level kernel (p3d_debug_set_stamp_level(l), l >= 2): one record per WAVE of the launch, written
 // for the wave's first batch -- 0 start, 1 queue read, 2 closest hit, 3 shading, 4 emit / pair combine -- then 5 = the wave
 // is done and 6 = the number of batches it ran
+// (only in builds with -DP3D_STAMPS -- `make stamps`, libp3d_hip_stamps.so, tools/wave_timeline.py: the checks cost the
+//  deeper-level kernel 25 spilled scalar registers, and that kernel is bound by instruction issue)
 __device__ __forceinline__ bool stamps_on(const LaunchParams& P) {
+#ifdef P3D_STAMPS
     return P.dbg_stamps && P.dbg_stamp_level == P.wf_level && (threadIdx.x & 63) == 0;
+#else
+    return false;
+#endif
 }
 __device__ __forceinline__ void stamp_wave(const LaunchParams& P, uint32_t wave_id, int k, bool first = true) {
     if (first && stamps_on(P)) stamp_record(P.dbg_stamps + (size_t)wave_id * 8, k);
@@ -345,11 +321,11 @@ __device__ __forceinline__ void stamp_wave(const LaunchParams& P, uint32_t wave_
 // grid, scene copied once per workgroup, every wave drawing 16x4 tiles from device counters with the next number
 // prefetched -- was measured and dropped: 520 us with one counter (a word saturates at ~88 returning atomics per
 // microsecond), 110 us with 64 counters on separate lines, against 50 us for this plain grid.)
-// (LDS scenes: up to 16 waves per workgroup -- LaunchParams::wg_waves of THIS launch -- because workgroups are handed
-//  out at ~200 per microsecond whatever their size (profiles/r03_timelines.txt: 8160 four-wave workgroups of config 2 take
-//  40 of the launch's 46 us to start, with half the wave slots empty), and a bigger workgroup shares one scene copy)
+// (Measured and dropped in round 3, profiles/r03_exp03_sharing_wg_levers.txt / r03_exp04_tiles_lpt_bound.txt: 8- and 16-wave
+//  workgroups -- level 1 of config 2 46 -> 51 -> 54 us -- and 2-4 tiles per workgroup one after the other: the waves of
+//  this launch start at ~830 per microsecond whatever the workgroup shape, and the loop's registers cost occupancy.)
 template <bool COUNT, bool LDS, int WALK, int OCC, bool STOCH = false>
-__global__ __launch_bounds__(LDS ? 1024 : 64) P3D_OCC(OCC) void wf_primary_kernel(const LaunchParams P) {
+__global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel(const LaunchParams P) {
     const uint32_t par = P.wf_ctrl[0] & 1u;                     // this pass's counter set (LaunchParams::wf_alt)
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) P.wf_ctrl[32] = par;
@@ -358,38 +334,30 @@ __global__ __launch_bounds__(LDS ? 1024 : 64) P3D_OCC(OCC) void wf_primary_kerne
         for (uint32_t i = threadIdx.x; i < 2u * (uint32_t)P.wf_shards; i += blockDim.x) other[i] = 0u;
     }
     const typename View<LDS>::type sv = View<LDS>::make(P);
+    int x, y, row, tile;
+    const bool valid = tile_pixel<!LDS>(P, x, y, row, &tile);
+    if (__ballot(valid) == 0) return;
+    const Shard sh = shard_of(P, (uint32_t)tile % (uint32_t)P.wf_shards, par);
     const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
-    uint32_t my_pixels = 0;
-    // wf_tiles_per_wg tiles per workgroup, one after the other (tile k of workgroup b = b + k * gridDim.x: far apart in the
-    // image, so the cheap and the expensive ones mix): a wave's fixed costs -- being launched, the scene copy, the
-    // launch parameters -- are paid once for all of them
-    for (int it = 0; it < P.wf_tiles_per_wg; it++) {
-        int x, y, row, tile;
-        const bool valid = tile_pixel(P, x, y, row, &tile, (int)(blockIdx.x + (uint32_t)it * gridDim.x));
-        if (__ballot(valid) == 0) continue;
-        const Shard sh = shard_of(P, (uint32_t)tile % (uint32_t)P.wf_shards, par);
-        const size_t p = (size_t)row * P.res_x + x;
-        const unsigned long long t_tile = P.tile_cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        stamp(P, tile, 0);
-        Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
-        if (valid) ray = camera_ray(P, x, y, P.wf_sample);
-        stamp(P, tile, 1);
-        const Hit h = find_closest<COUNT, WALK>(P, sv, ray, valid, tc, ctr);
-        stamp(P, tile, 2);
-        if (valid && P.hit_id && P.wf_sample == 0) P.hit_id[p] = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid;
-        // the random stream of a pixel sample is keyed by the pixel's place in the FULL frame, so a frame
-        // sharded over several GPUs draws the same numbers as on one
-        const uint32_t rng = STOCH ? rng_mix(rng_mix(P.seed, (uint32_t)(y * P.res_x + x)), (uint32_t)P.wf_sample) : 0u;
-        NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr, rng);
-        if (P.wf_fuse_last) o = fuse_last_level<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, o, valid, 1, 1.0f, tc, ctr);
-        stamp(P, tile, 3);
-        emit(P, sh, 1, valid, (uint32_t)p, 1.0f, o);
-        stamp(P, tile, 4);
-        if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
-        my_pixels += (valid && P.wf_sample == 0) ? 1u : 0u;
-    }
-    if (COUNT) flush_counters<COUNT>(P, ctr, my_pixels);
+    const size_t p = (size_t)row * P.res_x + x;
+    const unsigned long long t_tile = (!LDS && P.tile_cost) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    stamp(P, tile, 0);
+    Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
+    if (valid) ray = camera_ray(P, x, y, P.wf_sample);
+    stamp(P, tile, 1);
+    const Hit h = find_closest<COUNT, WALK>(P, sv, ray, valid, tc, ctr);
+    stamp(P, tile, 2);
+    if (valid && P.hit_id && P.wf_sample == 0) P.hit_id[p] = (h.ref == 0xFFFFFFFFu) ? -1 : (int32_t)h.sid;
+    // the random stream of a pixel sample is keyed by the pixel's place in the FULL frame, so a frame
+    // sharded over several GPUs draws the same numbers as on one
+    const uint32_t rng = STOCH ? rng_mix(rng_mix(P.seed, (uint32_t)(y * P.res_x + x)), (uint32_t)P.wf_sample) : 0u;
+    const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, valid, 1, 1.0f, tc, ctr, rng);
+    stamp(P, tile, 3);
+    emit(P, sh, 1, valid, (uint32_t)p, 1.0f, o);
+    stamp(P, tile, 4);
+    if (!LDS && P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
+    if (valid) flush_counters<COUNT>(P, ctr, P.wf_sample == 0 ? 1u : 0u);
 }
 
 // Lanes a wave of a deeper level uses: a short queue is spread over ALL the shard's waves with
@@ -454,9 +422,8 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
             if (stamps_on(P) && st1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_wave(P, wave_id, 1); }
             const Hit h = find_closest<COUNT, WALK>(P, sv, ray, live, tc, ctr);
             stamp_wave(P, wave_id, 2, st1);
-            NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
-                                                                              ctr, rng);
-            if (P.wf_fuse_last) o = fuse_last_level<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, o, live, P.wf_level, ior_1, tc, ctr);
+            const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
+                                                                                    ctr, rng);
             stamp_wave(P, wave_id, 3, st1);
             if (P.wf_pair_in) combine_pair(P, sh, live, link, o);
             else emit(P, sh, P.wf_level, live, link, ior_1, o);
@@ -502,9 +469,8 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
         const bool live = valid && link != kPairEmpty;
         const Hit h = find_closest<COUNT, WALK>(P, sv, ray, live, tc, ctr);
         stamp_wave(P, wave_id, 2, st1);
-        NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
-                                                                          ctr, rng);
-        if (P.wf_fuse_last) o = fuse_last_level<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, o, live, P.wf_level, ior_1, tc, ctr);
+        const NodeOut o = shade_hit<COUNT, WALK, typename View<LDS>::type, STOCH>(P, sv, ray, h, live, P.wf_level, ior_1, tc,
+                                                                                ctr, rng);
         stamp_wave(P, wave_id, 3, st1);
         if (P.wf_pair_in) combine_pair(P, sh, live, link, o);
         else emit(P, sh, P.wf_level, live, link, ior_1, o);
@@ -668,13 +634,13 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
         if (tid == 0) T->tile = atomicAdd(&P.tw_ctrl[0], 1u);
         __syncthreads();
         if ((int)T->tile >= P.n_tiles) {                         // workgroup-uniform
-            if (P.tile_cost && tid == 0 && prev_tile >= 0) P.tile_cost[prev_tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
+            if (!LDS && P.tile_cost && tid == 0 && prev_tile >= 0) P.tile_cost[prev_tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
             break;
         }
-        const int tile = P.tile_order ? (int)P.tile_order[T->tile] : (int)T->tile;     // (heaviest first, once measured)
-        if (tid == 0 && (P.tile_cost || P.dbg_stamps)) {
+        const int tile = (!LDS && P.tile_order) ? (int)P.tile_order[T->tile] : (int)T->tile;     // (heaviest first, once measured)
+        if (tid == 0 && ((!LDS && P.tile_cost) || P.dbg_stamps)) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (P.tile_cost && prev_tile >= 0) P.tile_cost[prev_tile] = (uint32_t)(now - t_tile);
+            if (!LDS && P.tile_cost && prev_tile >= 0) P.tile_cost[prev_tile] = (uint32_t)(now - t_tile);
             if (P.dbg_stamps) {                                  // diagnostic: one record per TILE (0 start, 1 end, 2 workgroup)
                 if (prev_tile >= 0) P.dbg_stamps[(size_t)prev_tile * 8 + 1] = now;
                 P.dbg_stamps[(size_t)tile * 8] = now;
@@ -920,9 +886,9 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kern
     const typename View<LDS>::type sv = View<LDS>::make(P);
     const int lane = threadIdx.x & 63;
     int x, y, row, tile;
-    const bool in_image = tile_pixel(P, x, y, row, &tile);
+    const bool in_image = tile_pixel<!LDS>(P, x, y, row, &tile);
     if (SHARED ? __ballot(in_image) == 0 : !in_image) return;   // no barriers below: early exit is safe
-    const unsigned long long t_tile = P.tile_cost ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long t_tile = (!LDS && P.tile_cost) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     stamp(P, tile, 0);
     uint32_t priv[PRIV > 0 ? PRIV : 1];
     uint32_t* wbase;
@@ -943,7 +909,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kern
             flush_counters<COUNT>(P, ctr, 1u);
         }
         stamp(P, tile, 4);
-        if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
+        if (!LDS && P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
         return;
     }
     if (P.spp == 0) {                                    // RT/main.cpp:756-775
@@ -963,7 +929,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kern
     if (P.hit_id) P.hit_id[p] = hid;
     flush_counters<COUNT>(P, ctr, 1u);
     stamp(P, tile, 4);              // (diagnostic; the wave has reconverged here: its slowest lane is done)
-    if (P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
+    if (!LDS && P.tile_cost && threadIdx.x == 0) P.tile_cost[tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
 }
 
 // per-column / per-row factors of the pixel-centre camera rays (one launch per resolution)
