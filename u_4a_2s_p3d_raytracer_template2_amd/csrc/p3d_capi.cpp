@@ -479,7 +479,10 @@ int run_wavefront_pass(p3d_scene* s, p3d_scene::Workspace& ws, hipStream_t strea
     const int D = P.max_depth;
     // scenes read from HBM wait on fetches most of the time: a register budget of 6 waves per SIMD measured 3 %
     // faster than the compiler's default there (10^6 primitives 3.19 -> 3.08 ms); LDS scenes keep the default
-    const int occ = s->occupancy ? s->occupancy : (lds ? 0 : 6);
+    // ... and since round 3 the LDS scenes' level kernels run at 6 too: the deeper-level kernel needs 82 VGPRs by default
+    // (5 waves per SIMD), 78 under that budget without a spill -- config 2 0.0720 -> 0.0692 ms/frame, config 4 on this
+    // schedule 5.30 -> 5.05 ms (profiles/r03_exp10_register_budgets.txt)
+    const int occ = s->occupancy ? s->occupancy : 6;
     const size_t n_counts = kCountWords;
     uint32_t* counts = (uint32_t*)ws.counts.p;                              // [level][shard] ray counts, then node counts
     // No clearing launch and nothing about a frame in host state (a captured frame can be replayed any number of
@@ -674,6 +677,8 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     P.ray_fx = (const float*)s->ray_tab.p; P.ray_fy = P.ray_fx + cam->res_x;
     P.max_depth = prm->max_depth; P.accel = prm->accel; P.spp = prm->spp;
     P.row_block = row_block; P.rank = rank; P.world = world;
+    P.row_block_shift = -1;
+    for (int sh = 4; sh < 20; sh++) if ((1 << sh) == row_block) P.row_block_shift = sh;
     P.local_rows = p3d_local_rows(cam->res_y, row_block, world);
     const int tile_rows = 4 * P.wg_waves;
     P.tiles_x = (cam->res_x + 15) / 16; P.tiles_y = P.local_rows / tile_rows;
@@ -756,7 +761,9 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     int tile_blocks = 0;
     // register budget of the tile kernel: scenes read from HBM run it at 5 waves per SIMD (with the work-sharing walk the
     // default allocation is 129 VGPRs: one over the step to 3 waves per SIMD, i.e. 3 workgroups per CU instead of 4)
-    const int tile_occ = s->occupancy ? s->occupancy : (lds_scene ? 0 : 5);
+    // LDS scenes too: 106 VGPRs by default (4 waves per SIMD), 96 with 3 spilled at 5: config 4 4.96 -> 4.75 ms; at 6 (80
+    // VGPRs, 17 spilled) 5.03 (profiles/r03_exp10_register_budgets.txt)
+    const int tile_occ = s->occupancy ? s->occupancy : 5;
     bool tile_ok = false;
     auto tile_query = [&]() -> int {                      // what the tile schedule can have with the walk in force
         tile_blocks = 0;

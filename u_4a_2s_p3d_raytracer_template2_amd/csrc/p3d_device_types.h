@@ -80,6 +80,7 @@ struct DeviceCounters {
         aabox_tests, plane_tests, pixels;
 };
 
+constexpr uint32_t kWfShards = 64;           // queue shards of the wavefront schedule (LaunchParams::wf_shards); == the wave size
 constexpr uint32_t kFeatSoftJitter = 1u, kFeatFuzzy = 2u;                  // LaunchParams::features
 constexpr uint32_t kShareDwords = 384;      // per-wave LDS of the work-sharing walk (p3d_traverse.h), behind the wave's stack slots
 
@@ -114,6 +115,7 @@ struct LaunchParams {
     int32_t max_depth, accel, spp;
     const float* samples;          // device copy of the host sample array or nullptr
     int32_t row_block, rank, world, local_rows;
+    int32_t row_block_shift;           // log2(row_block) when it is a power of two (the default 16 is), else -1: a division by a launch parameter is ~20 scalar instructions
     int32_t tiles_x, tiles_y, n_tiles, xcd_chunk, grid_blocks;
     // outputs (device)
     uint8_t* rgb8; float* rgb32f; int32_t* hit_id;
@@ -126,7 +128,7 @@ struct LaunchParams {
     // ray stays in its pixel's shard for its whole tree) so that the per-wave slot allocation
     // atomics spread over wf_shards counters instead of serialising on one word.  Pointers below
     // address shard 0; shard s is at + s * cap entries / + s counters.
-    int32_t wf_shards;
+    int32_t wf_shards;             // == kWfShards (the kernels use the constant: a modulo by a launch parameter is ~20 scalar instructions)
     uint32_t wf_cap_in, wf_cap_out, wf_ncap_parent, wf_ncap_self;    // entries per shard
     const RayRec* wf_rays_in;  const uint32_t* wf_count_in;      // level wf_level queue
     RayRec* wf_rays_out;       uint32_t* wf_count_out;           // level wf_level + 1 queue

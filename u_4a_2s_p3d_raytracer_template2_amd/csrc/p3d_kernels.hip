@@ -69,6 +69,12 @@ __device__ __forceinline__ void sink_sample(const LaunchParams& P, size_t p, V3 
     a[0] = c.x; a[1] = c.y; a[2] = c.z;
 }
 
+// row of the compact local buffer -> image row (this rank's row blocks are every world-th one)
+__device__ __forceinline__ int image_row(const LaunchParams& P, int row) {
+    const int blk = P.row_block_shift >= 0 ? (row >> P.row_block_shift) : row / P.row_block;
+    return (blk * P.world + P.rank) * P.row_block + (row - blk * P.row_block);
+}
+
 // "color += rayTracing(...).clamp()" over the samples in order, then "color / (4 * 4)"
 // (RT/main.cpp:797-800), for the rows [row0, row0 + rows) of the compact buffer
 __global__ __launch_bounds__(256) void sum_samples_kernel(const LaunchParams P, size_t first_px, size_t n_px) {
@@ -76,8 +82,8 @@ __global__ __launch_bounds__(256) void sum_samples_kernel(const LaunchParams P, 
         const size_t p = first_px + i;
         // rows past the image (the compact buffer is padded to whole row blocks) are never written:
         // a caller's device plane only holds res_y rows when world == 1 (include/p3d_hip.h)
-        const int row = (int)(p / (size_t)P.res_x), blk = row / P.row_block;
-        if ((blk * P.world + P.rank) * P.row_block + (row - blk * P.row_block) >= P.res_y) continue;
+        const int row = (int)(p / (size_t)P.res_x);
+        if (image_row(P, row) >= P.res_y) continue;
         V3 acc = mk(0.0f, 0.0f, 0.0f);
         for (int smp = 0; smp < P.wf_nsamples; smp++) {
             const float* a = P.wf_planes + (size_t)smp * P.wf_plane_stride + 3 * p;
@@ -91,25 +97,34 @@ __global__ __launch_bounds__(256) void sum_samples_kernel(const LaunchParams P, 
 template <bool ORDERED = false>
 __device__ __forceinline__ bool tile_pixel(const LaunchParams& P, int& x, int& y, int& row, int* tile_out = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // XCD-aware tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
-    // share one, each XCD has its own L2), so XCD k is given CHUNKS of xcd_chunk consecutive
-    // tiles: chunk c goes to XCD c % 8.  xcd_chunk = 1 is the identity map (best load balance),
-    // larger chunks trade balance for L2 locality on scenes whose BVH does not fit one L2.
-    const int bid = blockIdx.x;
-    const int j = bid >> 3;
-    int tile = ((j / P.xcd_chunk) * 8 + (bid & 7)) * P.xcd_chunk + (j % P.xcd_chunk);
     x = 0; y = 0; row = 0;
-    if (tile_out) *tile_out = tile;
-    if (tile >= P.n_tiles) return false;
-    if (ORDERED && P.tile_order) {            // heaviest first (scenes read from HBM, once a frame has measured the tiles)
-        tile = (int)P.tile_order[tile];
+    int tx, ty, tile;
+    if (!ORDERED && gridDim.y > 1) {
+        // 2-D launch (identity tile map, xcd_chunk == 1): blockIdx.x / .y ARE the tile's column and row -- no division by
+        // launch parameters on the scalar unit (three of them cost this kernel ~60 of its ~350 scalar instructions per wave)
+        tx = blockIdx.x; ty = blockIdx.y;
+        tile = ty * P.tiles_x + tx;
         if (tile_out) *tile_out = tile;
+        ty += P.wf_tile_row0;
+    } else {
+        // XCD-aware tile map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
+        // share one, each XCD has its own L2), so XCD k is given CHUNKS of xcd_chunk consecutive
+        // tiles: chunk c goes to XCD c % 8.  xcd_chunk = 1 is the identity map (best load balance),
+        // larger chunks trade balance for L2 locality on scenes whose BVH does not fit one L2.
+        const int bid = blockIdx.x;
+        const int j = bid >> 3;
+        tile = P.xcd_chunk == 1 ? bid : ((j / P.xcd_chunk) * 8 + (bid & 7)) * P.xcd_chunk + (j % P.xcd_chunk);
+        if (tile_out) *tile_out = tile;
+        if (tile >= P.n_tiles) return false;
+        if (ORDERED && P.tile_order) {            // heaviest first (scenes read from HBM, once a frame has measured the tiles)
+            tile = (int)P.tile_order[tile];
+            if (tile_out) *tile_out = tile;
+        }
+        tx = tile % P.tiles_x; ty = P.wf_tile_row0 + tile / P.tiles_x;
     }
-    const int tx = tile % P.tiles_x, ty = P.wf_tile_row0 + tile / P.tiles_x;
     x = tx * 16 + (lane & 15);
     row = ty * (P.wg_waves * 4) + (lane >> 4) + wave * 4;         // row in the compact local buffer
-    const int blk = row / P.row_block;
-    y = (blk * P.world + P.rank) * P.row_block + (row - blk * P.row_block);
+    y = image_row(P, row);
     return x < P.res_x && y < P.res_y;
 }
 
@@ -131,13 +146,13 @@ struct Shard {
 };
 // the counter arrays of this launch under pass parity `par` (see LaunchParams::wf_alt)
 __device__ __forceinline__ const uint32_t* count_in_array(const LaunchParams& P, uint32_t par) {
-    return P.wf_level == 2 ? P.wf_alt + (size_t)(par * 2u) * (uint32_t)P.wf_shards : P.wf_count_in;
+    return P.wf_level == 2 ? P.wf_alt + (size_t)(par * 2u) * kWfShards : P.wf_count_in;
 }
 __device__ __forceinline__ uint32_t* count_out_array(const LaunchParams& P, uint32_t par) {
-    return P.wf_level == 1 ? P.wf_alt + (size_t)(par * 2u) * (uint32_t)P.wf_shards : P.wf_count_out;
+    return P.wf_level == 1 ? P.wf_alt + (size_t)(par * 2u) * kWfShards : P.wf_count_out;
 }
 __device__ __forceinline__ uint32_t* ncount_self_array(const LaunchParams& P, uint32_t par) {
-    return P.wf_level == 1 ? P.wf_alt + (size_t)(par * 2u + 1u) * (uint32_t)P.wf_shards : P.wf_ncount_self;
+    return P.wf_level == 1 ? P.wf_alt + (size_t)(par * 2u + 1u) * kWfShards : P.wf_ncount_self;
 }
 __device__ __forceinline__ Shard shard_of(const LaunchParams& P, uint32_t s, uint32_t par) {
     Shard h;
@@ -327,17 +342,17 @@ __device__ __forceinline__ void stamp_wave(const LaunchParams& P, uint32_t wave_
 template <bool COUNT, bool LDS, int WALK, int OCC, bool STOCH = false>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel(const LaunchParams P) {
     const uint32_t par = P.wf_ctrl[0] & 1u;                     // this pass's counter set (LaunchParams::wf_alt)
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
         if (threadIdx.x == 0) P.wf_ctrl[32] = par;
         for (uint32_t i = threadIdx.x; i < P.wf_clear_words; i += blockDim.x) P.wf_clear[i] = 0u;
-        uint32_t* other = P.wf_alt + (size_t)((1u - par) * 2u) * (uint32_t)P.wf_shards;
-        for (uint32_t i = threadIdx.x; i < 2u * (uint32_t)P.wf_shards; i += blockDim.x) other[i] = 0u;
+        uint32_t* other = P.wf_alt + (size_t)((1u - par) * 2u) * kWfShards;
+        for (uint32_t i = threadIdx.x; i < 2u * kWfShards; i += blockDim.x) other[i] = 0u;
     }
     const typename View<LDS>::type sv = View<LDS>::make(P);
     int x, y, row, tile;
     const bool valid = tile_pixel<!LDS>(P, x, y, row, &tile);
     if (__ballot(valid) == 0) return;
-    const Shard sh = shard_of(P, (uint32_t)tile % (uint32_t)P.wf_shards, par);
+    const Shard sh = shard_of(P, (uint32_t)tile % kWfShards, par);
     const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
     const size_t p = (size_t)row * P.res_x + x;
@@ -378,7 +393,7 @@ __device__ __forceinline__ uint32_t wave_width(uint32_t count, uint32_t waves_pe
 // level >= 2: one queued ray per lane, persistent waves striding over the queue
 template <bool COUNT, bool LDS, int WALK, int OCC, bool STOCH = false>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kernel(const LaunchParams P) {
-    const uint32_t S = (uint32_t)P.wf_shards;
+    constexpr uint32_t S = kWfShards;
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const int lane = threadIdx.x & 63;
     const uint32_t par = P.wf_ctrl[32] & 1u;                    // set by the level-1 launch of this pass
@@ -482,7 +497,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
 
 // walk one level back up: node = color + (refl_ret*KR*spec + refr_ret*(1-KR)), RT/main.cpp:719
 __global__ __launch_bounds__(256) void wf_resolve_kernel(const LaunchParams P) {
-    const uint32_t S = (uint32_t)P.wf_shards;
+    constexpr uint32_t S = kWfShards;
     const Shard sh = shard_of(P, blockIdx.x % S, P.wf_ctrl[32] & 1u);
     const uint32_t count = *sh.ncount_self;
     const uint32_t per_shard = gridDim.x / S;
@@ -509,7 +524,7 @@ __global__ __launch_bounds__(1024) void wf_resolve_fused_kernel(const LaunchPara
         sh.nodes_self = R.nodes[l] + (size_t)s * R.cap[l];
         sh.nodes_parent = l > 1 ? R.nodes[l - 1] + (size_t)s * R.cap[l - 1] : nullptr;
         sh.ncount_self = nullptr;
-        const uint32_t count = l == 1 ? (P.wf_alt + (size_t)(par * 2u + 1u) * (uint32_t)P.wf_shards)[s] : R.ncount[l][s];
+        const uint32_t count = l == 1 ? (P.wf_alt + (size_t)(par * 2u + 1u) * kWfShards)[s] : R.ncount[l][s];
         for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
             const float4* nd = reinterpret_cast<const float4*>(sh.nodes_self + i);
             float4 a = nd[0], b = nd[1], c = nd[2];
@@ -543,8 +558,22 @@ struct TileLds {
     float acc[3 * kTilePx];               // sum of the clamped sample colours of each pixel (spp > 0)
 };
 
+// LDS scenes: the first kTileLdsRays queued rays of a level stay in LDS -- two buffers, written and read alternately
+// by consecutive levels (a level's own barrier separates them); only what does not fit goes through the workgroup's
+// slot in HBM.  A 16x16 tile of config 4 queues ~750 rays per sample pass, ~300 of them for its largest level: the
+// ray half of the queue traffic (11.6 GB per frame in round 2, profiles/r02_config4_pmc.json) stays on the CU.
+constexpr uint32_t kTileLdsRays = 256;
+constexpr uint32_t kTileLdsRayDwords = 2u * kTileLdsRays * 8u;        // 16 KB
+
 struct TileCtx {
     uint32_t lds_off;                     // dword offset of the TileLds inside p3d_lds
+    uint32_t lq_off;                      // dword offset of the LDS ray buffers (0 = none: scenes read from HBM)
+    // ray slot `i` of level `l`: in LDS below kTileLdsRays (when the kernel has the buffers), else in the HBM slot
+    __device__ __forceinline__ float4* ray_slot(int l, uint32_t i) const {
+        if (lq_off != 0u && i < kTileLdsRays)
+            return reinterpret_cast<float4*>(p3d_lds + lq_off) + ((uint32_t)(l & 1) * kTileLdsRays + i) * 2u;
+        return reinterpret_cast<float4*>(rays + tile_ray_offset(l) + i);
+    }
     RayRec* rays; NodeRec* nodes; uint32_t* keys;     // this workgroup's slot
     int tx, ty;                           // tile coordinates
     __device__ __forceinline__ TileLds* lds() const { return reinterpret_cast<TileLds*>(p3d_lds + lds_off); }
@@ -596,17 +625,16 @@ __device__ __forceinline__ void tile_emit(const LaunchParams& P, const TileCtx& 
     nd[0] = make_float4(o.color.x, o.color.y, o.color.z, o.KR);
     nd[1] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(o.mat));
     nd[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(link));
-    RayRec* out = X.rays + tile_ray_offset(level + 1);
     if (o.has_refl) {                                           // reflection child keeps ior_1
         const uint32_t slot = ray_base + lane_rank(m_refl);
-        float4* rq = reinterpret_cast<float4*>(out + slot);
+        float4* rq = X.ray_slot(level + 1, slot);
         rq[0] = make_float4(o.refl.o.x, o.refl.o.y, o.refl.o.z, ior_1);
         rq[1] = make_float4(o.refl.d.x, o.refl.d.y, o.refl.d.z, __uint_as_float(my_node));
         if (X.keys) X.keys[tile_ray_offset(level + 1) + slot] = o.rng_refl;
     }
     if (o.has_refr) {
         const uint32_t slot = ray_base + n_refl + lane_rank(m_refr);
-        float4* rq = reinterpret_cast<float4*>(out + slot);
+        float4* rq = X.ray_slot(level + 1, slot);
         rq[0] = make_float4(o.refr.o.x, o.refr.o.y, o.refr.o.z, o.newIor);
         rq[1] = make_float4(o.refr.d.x, o.refr.d.y, o.refr.d.z, __uint_as_float(my_node | kLinkRefr));
         if (X.keys) X.keys[tile_ray_offset(level + 1) + slot] = o.rng_refr;
@@ -620,6 +648,7 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
     const TravCtx tc = wave_stack<LDS>(P, 0);
     TileCtx X;
     X.lds_off = View<LDS>::scene_dwords(P) + 4u * P.trav_stack_dwords;
+    X.lq_off = LDS ? X.lds_off + (uint32_t)((sizeof(TileLds) + 15) / 16) * 4u : 0u;
     uint8_t* slot = P.tw_base + (size_t)blockIdx.x * P.tw_slot_bytes;
     X.rays = reinterpret_cast<RayRec*>(slot + P.tw_rays_off);
     X.nodes = reinterpret_cast<NodeRec*>(slot + P.tw_nodes_off);
@@ -652,8 +681,7 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
         X.tx = tile % P.tiles_x; X.ty = tile / P.tiles_x;
         const int x = X.tx * 16 + (lane & 15);
         const int row = X.ty * 16 + wave * 4 + (lane >> 4);      // row in the compact local buffer
-        const int blk = row / P.row_block;
-        const int y = (blk * P.world + P.rank) * P.row_block + (row - blk * P.row_block);
+        const int y = image_row(P, row);
         const bool inside = x < P.res_x && y < P.res_y;
         const size_t p = (size_t)row * P.res_x + x;
         if (P.spp > 0) { T->acc[3 * tid] = 0.0f; T->acc[3 * tid + 1] = 0.0f; T->acc[3 * tid + 2] = 0.0f; }
@@ -665,7 +693,7 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
             // is instantiated once per kernel.
             for (int l = 1; l <= D; l++) {
                 const uint32_t n = l == 1 ? kTilePx : T->n_rays[l];
-                const RayRec* in = X.rays + tile_ray_offset(l < 2 ? 2 : l);
+
                 for (uint32_t base = (uint32_t)wave * 64u; base < n; base += 256u) {
                     const uint32_t i = base + lane;
                     bool valid; uint32_t link = (uint32_t)tid, rng = 0; float ior_1 = 1.0f;
@@ -677,7 +705,7 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
                     } else {
                         valid = i < n;
                         if (valid) {
-                            const float4* rq = reinterpret_cast<const float4*>(in + i);
+                            const float4* rq = X.ray_slot(l, i);
                             const float4 a = rq[0], b = rq[1];
                             ray.o = mk(a.x, a.y, a.z); ray.d = mk(b.x, b.y, b.z);
                             ior_1 = a.w; link = __float_as_uint(b.w);
@@ -1100,7 +1128,11 @@ hipError_t launch_tree(const LaunchParams& P, bool count, bool lds, int occ, boo
                              dim3(64 * P.wg_waves), tree_kernel_lds_bytes(P, lds), stream);
 }
 hipError_t launch_wf_primary(const LaunchParams& P, bool count, bool lds, int walk, int occ, hipStream_t stream) {
-    return launch_by_pointer(wf_primary_fn(count, lds, walk, occ, P.features != 0), P, dim3((unsigned)P.grid_blocks),
+    // identity tile map and no learned order: a 2-D grid, blockIdx = (tile column, tile row) -- see tile_pixel()
+    // (LDS scenes only: the kernels of scenes read from HBM number their tiles through the learned order)
+    const bool grid2d = lds && P.xcd_chunk == 1 && P.wf_tile_rows > 1 && P.tiles_x * P.wf_tile_rows == P.n_tiles;
+    const dim3 grid = grid2d ? dim3((unsigned)P.tiles_x, (unsigned)P.wf_tile_rows) : dim3((unsigned)P.grid_blocks);
+    return launch_by_pointer(wf_primary_fn(count, lds, walk, occ, P.features != 0), P, grid,
                              dim3(64 * P.wg_waves), wavefront_lds_bytes(P, lds), stream);
 }
 hipError_t launch_wf_secondary(const LaunchParams& P, bool count, bool lds, int walk, int occ, unsigned waves,
@@ -1121,7 +1153,7 @@ hipError_t wf_resident_waves(const LaunchParams& P, bool primary, bool count, bo
 }
 // tile schedule: 256-thread workgroups
 size_t tile_kernel_lds_bytes(const LaunchParams& P, bool lds) {
-    return scene_lds_bytes(P, lds) + (size_t)P.trav_stack_dwords * 4 * 4 + sizeof(TileLds);
+    return scene_lds_bytes(P, lds) + (size_t)P.trav_stack_dwords * 4 * 4 + (sizeof(TileLds) + 15) / 16 * 16 + (lds ? (size_t)kTileLdsRayDwords * 4 : 0);
 }
 // workgroups of this variant that can be resident on the whole device (persistent grid size)
 hipError_t tile_kernel_resident_blocks(const LaunchParams& P, bool count, bool lds, int walk, int occ, int* blocks) {
