@@ -128,6 +128,13 @@ typedef struct p3d_render_params {
  * MOTION_BLUR only stamps rays with a time no object reads, so it has no switch. */
 #define P3D_FEATURE_SOFT_SHADOW 1u
 #define P3D_FEATURE_FUZZY_REFLECTION 2u
+/* A ray that hits nothing returns Scene::GetSkyboxColor(ray) (RT/scene.cpp:383-461) from the cube map given to
+ * p3d_scene_set_skybox() instead of the background colour.  The reference holds this function and the `env` loader
+ * command (RT/scene.cpp:652-658) but never calls the former -- its rayTracing() returns bgColor on a miss
+ * (RT/main.cpp:582) -- so this switch is what the function is evidently there for, off by default.
+ * The lookup itself is bit-exact against the reference's object code (tests/test_oracle_vs_ref.py).  Like the other
+ * features it needs the tile or the wavefront schedule. */
+#define P3D_FEATURE_SKYBOX 4u
 
 #define P3D_FLAG_COUNTERS 1u     /* accumulate p3d_counters on the device (slower kernels)  */
 /* Kernel schedules: three ways to run the same per-node code, bit-identical frames.  Which one p3d_render() uses
@@ -211,6 +218,11 @@ int         p3d_device_count(int* count);
 int p3d_scene_create(const p3d_scene_desc* desc, const p3d_build_opts* opts, int device,
                      p3d_scene** out);
 int p3d_scene_destroy(p3d_scene* scene);
+/* Replaces Scene::LoadSkybox (RT/scene.cpp:333-381; DevIL image loading stays with the caller): the six faces in the
+ * reference's order right, left, top, bottom, front, back, each res_x[i] x res_y[i] pixels of bytes_per_pixel[i] (3 or
+ * 4) bytes, rows bottom-up (the reference loads them with a lower-left origin).  HOST pointers; copied to the device. */
+int p3d_scene_set_skybox(p3d_scene* scene, const uint8_t* const faces[6], const uint32_t res_x[6], const uint32_t res_y[6],
+                         const uint32_t bytes_per_pixel[6]);
 int p3d_scene_get_stats(const p3d_scene* scene, p3d_scene_stats* out);
 
 /* Rows of the compact per-rank tile buffer: ceil(n_row_blocks / world) * row_block, the

@@ -18,7 +18,8 @@ SPHERE, TRIANGLE, BOX, PLANE = 0, 1, 2, 3
 class Params(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("accel", C.c_int32), ("spp", C.c_int32),
                 ("seed", C.c_uint32), ("threads", C.c_int32), ("break_fixed", C.c_int32),
-                ("y0", C.c_int32), ("y1", C.c_int32), ("soft_shadow", C.c_int32), ("fuzzy_reflection", C.c_int32)]
+                ("y0", C.c_int32), ("y1", C.c_int32), ("soft_shadow", C.c_int32), ("fuzzy_reflection", C.c_int32),
+                ("skybox", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -60,6 +61,8 @@ def lib():
         L.p3o_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(Counters)]
         L.p3o_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, fp, fp, fp]
+        L.p3o_scene_set_skybox.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.p3o_skybox_color.argtypes = [C.c_void_p, fp, fp]
         L.p3o_intersect.restype = C.c_int
         L.p3o_intersect.argtypes = [C.c_int, fp, fp, fp, fp, fp]
         L.p3o_aabb_intercepts.restype = C.c_int
@@ -175,14 +178,29 @@ class Scene:
         lib().p3o_primary_ray_lens(self.h, lx, ly, px, py, _f(o), _f(d))
         return o, d
 
+    def set_skybox(self, faces):
+        """faces: six uint8 arrays [H, W, 3 or 4] (right, left, top, bottom, front, back; row 0 = bottom row)."""
+        faces = [np.ascontiguousarray(f, np.uint8) for f in faces]
+        ptrs = (C.c_void_p * 6)(*[f.ctypes.data for f in faces])
+        rx = (C.c_uint32 * 6)(*[f.shape[1] for f in faces])
+        ry = (C.c_uint32 * 6)(*[f.shape[0] for f in faces])
+        bpp = (C.c_uint32 * 6)(*[f.shape[2] for f in faces])
+        lib().p3o_scene_set_skybox(self.h, ptrs, rx, ry, bpp)
+
+    def skybox_color(self, d):
+        d = f3(d)
+        c = np.zeros(3, np.float32)
+        lib().p3o_skybox_color(self.h, _f(d), _f(c))
+        return c
+
     def render(self, max_depth=4, accel=-1, spp=-1, seed=12345, threads=1, break_fixed=0,
-               want_f32=True, want_hit=True, y0=0, y1=0, soft_shadow=False, fuzzy_reflection=False):
+               want_f32=True, want_hit=True, y0=0, y1=0, soft_shadow=False, fuzzy_reflection=False, skybox=False):
         """Returns dict(rgb8 [H,W,3] u8 bottom row first, rgb32f, hit_id, counters)."""
         W, H = self.res_x, self.res_y
         rgb8 = np.zeros((H, W, 3), np.uint8)
         f32 = np.zeros((H, W, 3), np.float32) if want_f32 else None
         hid = np.full((H, W), -2, np.int32) if want_hit else None
-        prm = Params(max_depth, accel, spp, seed, threads, break_fixed, y0, y1, int(soft_shadow), int(fuzzy_reflection))
+        prm = Params(max_depth, accel, spp, seed, threads, break_fixed, y0, y1, int(soft_shadow), int(fuzzy_reflection), int(skybox))
         ctr = Counters()
         rc = lib().p3o_render(self.h, C.byref(prm), rgb8.ctypes.data,
                               f32.ctypes.data if want_f32 else None,

@@ -620,7 +620,41 @@ struct p3o_scene {
     bool parse_ok = true;
     RefBVH bvh; bool bvh_built = false;
     RefGrid grid; bool grid_built = false;
+    // Scene::skybox_img (RT/scene.h:190-195): right, left, top, bottom, front, back
+    struct Face { std::vector<uint8_t> img; unsigned resX = 0, resY = 0, BPP = 3; } skybox_img[6];
 };
+
+// Scene::GetSkyboxColor, RT/scene.cpp:383-461 (dead code in the reference: nothing calls it).  Same
+// expressions in the same types: "double invMa = 1 / ma" is a FLOAT division widened afterwards; s and t are formed in
+// double and rounded once; the two clamping lines (:450,452) are expression statements without effect; u8tofloat
+// divides by 255.99f (RT/maths.h:120-123).
+static Col skybox_color(const p3o_scene* sc, const V3& dir) {
+    const V3 c = dir;                                   // "skybox indexed by the ray direction"
+    float ma; int side;
+    if (fabs(c.x) > fabs(c.y)) { ma = fabs(c.x); side = c.x >= 0 ? 1 : 0; }       // LEFT at X = +1, RIGHT at X = -1
+    else { ma = fabs(c.y); side = c.y >= 0 ? 2 : 3; }                             // TOP / BOTTOM
+    if (fabs(c.z) > ma) { ma = fabs(c.z); side = c.z >= 0 ? 4 : 5; }              // FRONT / BACK
+    float scx = 0, tcx = 0;
+    switch (side) {
+    case 0: scx = -c.z; tcx = c.y; break;
+    case 1: scx = c.z; tcx = c.y; break;
+    case 2: scx = -c.x; tcx = -c.z; break;
+    case 3: scx = -c.x; tcx = c.z; break;
+    case 4: scx = -c.x; tcx = c.y; break;
+    case 5: scx = c.x; tcx = c.y; break;
+    }
+    double invMa = 1 / ma;
+    float s = (scx * invMa + 1) / 2;
+    float t = (tcx * invMa + 1) / 2;
+    const p3o_scene::Face& F = sc->skybox_img[side];
+    unsigned width = F.resX, height = F.resY, bytesperpixel = F.BPP;
+    unsigned xp = int((width - 1) * s);
+    unsigned yp = int((height - 1) * t);
+    size_t at = ((size_t)yp * width + xp) * bytesperpixel;
+    if (at + 2 >= F.img.size()) return Col(0, 0, 0);    // (a direction with NaNs indexes outside the image: the reference would read wild memory)
+    auto u8tofloat = [](uint8_t x) { return (float)(x / 255.99f); };
+    return Col(u8tofloat(F.img[at]), u8tofloat(F.img[at + 1]), u8tofloat(F.img[at + 2]));
+}
 
 namespace {
 
@@ -644,6 +678,7 @@ struct Tracer {
     int32_t last_primary_hit;
     // distribution-ray-tracing switches (compile-time false in the reference, RT/main.cpp:40-45)
     bool soft_shadow = false, fuzzy_reflection = false;
+    bool skybox = false;                           // a miss returns Scene::GetSkyboxColor(ray) instead of the background colour
     int spp = 0;                                   // globalSamplesPerPixel; ANTI_ALIASING == spp > 0 (RT/main.cpp:943)
     int offset_for_shadowx = 0, offset_for_shadowy = 0;                  // RT/main.cpp:101,779-780
 
@@ -705,7 +740,7 @@ struct Tracer {
             if (closest >= 0) hit_point = ray.o + ray.d * closest_t;
         }
         if (primary) last_primary_hit = closest;
-        if (closest < 0) return sc->bg;
+        if (closest < 0) return skybox ? skybox_color(sc, ray.d) : sc->bg;   // SURVEY Q8 (the reference: always bgColor)
 
         Prim& O = (*prims)[closest];
         const Mat& M = sc->mats[O.material];
@@ -1026,7 +1061,7 @@ int p3o_render(p3o_scene* sc, const p3o_params* prm, uint8_t* rgb8, float* rgb32
         srand(prm->seed);                                                 // RT/main.cpp:747 (every frame)
         Tracer T; T.sc = sc; T.prims = &sc->prims; T.bvh = &sc->bvh; T.grid = &sc->grid;
         T.accel = accel; T.max_depth = prm->max_depth; T.break_fixed = prm->break_fixed != 0;
-        T.soft_shadow = prm->soft_shadow != 0; T.fuzzy_reflection = prm->fuzzy_reflection != 0; T.spp = (int)spp;
+        T.soft_shadow = prm->soft_shadow != 0; T.fuzzy_reflection = prm->fuzzy_reflection != 0; T.spp = (int)spp; T.skybox = prm->skybox != 0;
         T.last_primary_hit = -1;
         sc->bvh.hit_stack.clear();
         render_rows(T, y0, y1, spp, rgb8, rgb32f, hit_id);
@@ -1043,7 +1078,7 @@ int p3o_render(p3o_scene* sc, const p3o_params* prm, uint8_t* rgb8, float* rgb32
                 RefGrid grid = sc->grid; grid.prims = &priv;
                 Tracer T; T.sc = sc; T.prims = &priv; T.bvh = &bvh; T.grid = &grid;
                 T.accel = accel; T.max_depth = prm->max_depth; T.break_fixed = prm->break_fixed != 0;
-        T.soft_shadow = prm->soft_shadow != 0; T.fuzzy_reflection = prm->fuzzy_reflection != 0; T.spp = (int)spp;
+        T.soft_shadow = prm->soft_shadow != 0; T.fuzzy_reflection = prm->fuzzy_reflection != 0; T.spp = (int)spp; T.skybox = prm->skybox != 0;
                 T.last_primary_hit = -1;
                 const int blk = 8;
                 for (int b = y0 / blk; b * blk < y1; b++) {
@@ -1059,6 +1094,19 @@ int p3o_render(p3o_scene* sc, const p3o_params* prm, uint8_t* rgb8, float* rgb32
     }
     if (ctr) *ctr = total;
     return 0;
+}
+
+void p3o_scene_set_skybox(p3o_scene* sc, const uint8_t* const faces[6], const uint32_t* res_x, const uint32_t* res_y,
+                          const uint32_t* bytes_per_pixel) {
+    for (int i = 0; i < 6; i++) {
+        p3o_scene::Face& F = sc->skybox_img[i];
+        F.resX = res_x[i]; F.resY = res_y[i]; F.BPP = bytes_per_pixel[i];
+        F.img.assign(faces[i], faces[i] + (size_t)F.resX * F.resY * F.BPP);
+    }
+}
+void p3o_skybox_color(const p3o_scene* sc, const float* d, float* rgb3) {
+    Col c = skybox_color(sc, V3(d[0], d[1], d[2]));
+    rgb3[0] = c.r; rgb3[1] = c.g; rgb3[2] = c.b;
 }
 
 // one rayTracing(ray, 1, 1.0) call (RT/main.cpp:530) on an arbitrary ray, for the shading KATs

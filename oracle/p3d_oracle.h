@@ -42,6 +42,8 @@ typedef struct p3o_params {
     int32_t soft_shadow;  /* SOFT_SHADOW of RT/main.cpp:41: 4x4 area-light grid when spp == 0, one
                              jittered light sample per pixel sample otherwise (RT/main.cpp:598-625)  */
     int32_t fuzzy_reflection; /* FUZZY_REFLECTION of RT/main.cpp:43 (RT/main.cpp:651-660)            */
+    int32_t skybox;       /* 1 = a miss returns Scene::GetSkyboxColor(ray) (RT/scene.cpp:383-461; never called by
+                             the reference itself) from the cube map given to p3o_scene_set_skybox */
 } p3o_params;
 
 typedef struct p3o_counters {
@@ -72,6 +74,12 @@ void       p3o_scene_camera(const p3o_scene*, float* out19);
  * (first sample when spp>0). Returns 0 on success. */
 int p3o_render(p3o_scene*, const p3o_params*, uint8_t* rgb8, float* rgb32f,
                int32_t* hit_id, p3o_counters* ctr);
+
+/* The six cube-map faces Scene::LoadSkybox would hold (RT/scene.cpp:333-381: right, left, top, bottom, front, back;
+ * rows bottom-up, 3 or 4 bytes per pixel); copied.  p3o_skybox_color = Scene::GetSkyboxColor (RT/scene.cpp:383-461). */
+void p3o_scene_set_skybox(p3o_scene*, const uint8_t* const faces[6], const uint32_t* res_x, const uint32_t* res_y,
+                          const uint32_t* bytes_per_pixel);
+void p3o_skybox_color(const p3o_scene*, const float* dir3, float* rgb3);
 
 /* one rayTracing(ray, 1, 1.0) call on an arbitrary ray (unclamped colour) */
 void p3o_trace(p3o_scene*, int accel, int max_depth, int soft_shadow, const float* o3, const float* d3,

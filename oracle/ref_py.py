@@ -74,6 +74,8 @@ def lib(depth=4):
     L.ref_scene_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_ulonglong)]
     L.ref_scene_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, fp, fp]
+    L.ref_skybox_colors.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_int,
+                                    C.c_void_p, C.c_void_p]
     _libs[depth] = L
     return L
 
@@ -169,3 +171,17 @@ class RefScene:
         c = np.zeros(3, np.float32)
         self.L.ref_scene_trace(self.h, int(accel), int(soft_shadow), F(o), F(d), F(c))
         return c
+
+
+def skybox_colors(faces, dirs, depth=4):
+    """Scene::GetSkyboxColor (RT/scene.cpp:383-461, the reference's own object code) for n directions.
+    faces: six uint8 arrays [H, W, 3 or 4] in the order right, left, top, bottom, front, back (RT/scene.cpp:337)."""
+    faces = [np.ascontiguousarray(f, np.uint8) for f in faces]
+    dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+    out = np.zeros_like(dirs)
+    ptrs = (C.c_void_p * 6)(*[f.ctypes.data for f in faces])
+    rx = (C.c_uint * 6)(*[f.shape[1] for f in faces])
+    ry = (C.c_uint * 6)(*[f.shape[0] for f in faces])
+    bpp = (C.c_uint * 6)(*[f.shape[2] for f in faces])
+    lib(depth).ref_skybox_colors(ptrs, rx, ry, bpp, len(dirs), dirs.ctypes.data, out.ctypes.data)
+    return out

@@ -46,6 +46,14 @@ def assert_rgb8_equal(got, ref, name=""):
     return n
 
 
+def synthetic_cube_map(seed=5):
+    """Six faces of different sizes and pixel widths (right, left, top, bottom, front, back): a synthetic stand-in for the
+    skybox JPEGs the reference's asset directory does not ship (`env skybox1`, directory missing)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    return [rng.integers(0, 256, (h, w, b), dtype=np.uint8) for (h, w, b) in ((37, 53, 3), (64, 64, 4), (16, 128, 3), (50, 50, 3), (33, 17, 4), (8, 8, 3))]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -9,7 +9,7 @@ holds no output with these switches on (they are compile-time false there)."""
 import numpy as np
 import pytest
 
-from conftest import scene_path
+from conftest import scene_path, synthetic_cube_map, assert_rgb8_equal
 from oracle import oracle_py as O
 import u_4a_2s_p3d_raytracer_template2_amd as P
 from u_4a_2s_p3d_raytracer_template2_amd import multigpu as MG
@@ -39,6 +39,35 @@ def test_soft_shadow_grid_matches_oracle(name, accel, depth):
         d8 = np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int))
         assert d8.max() <= 1 and (d8 != 0).mean() <= 1e-3
     ds.close()
+
+
+@pytest.mark.parametrize("name,accel,depth", [("mount_low", 2, 4), ("balls_low", 0, 3), ("balls_box", 1, 3), ("dragon", 2, 3)])
+def test_skybox_frames_match_oracle(name, accel, depth):
+    """P3D_FEATURE_SKYBOX: rays that hit nothing return Scene::GetSkyboxColor(ray) (RT/scene.cpp:383-461) from a synthetic
+    cube map (the reference's asset directory ships none).  The lookup is pinned bit for bit against the reference's
+    object code on the CPU (tests/test_oracle_vs_ref.py); here whole frames -- primary misses, reflected and "refracted"
+    misses -- against the oracle with the same switch, on both schedules that carry features and both scene placements."""
+    sc, hs, ds = load(name)
+    faces = synthetic_cube_map()
+    sc.set_skybox(faces)
+    ds.set_skybox(faces)
+    ref = sc.render(max_depth=depth, accel=accel, spp=0, skybox=True, threads=8 if accel != 1 else 1)
+    plain = sc.render(max_depth=depth, accel=accel, spp=0)
+    assert (ref["rgb8"] != plain["rgb8"]).any(axis=2).mean() > 0.05            # the sky shows (and reflects)
+    for kw in (dict(), dict(wavefront=True), dict(tile=True), dict(wavefront=True, no_lds=True), dict(tile=True, no_lds=True, private_walk=True)):
+        out = ds.render(hs.camera(), max_depth=depth, accel=accel, spp=0, skybox=True, counters=True, **kw)
+        assert np.array_equal(out["hit_id"], ref["hit_id"]), kw
+        assert np.abs(out["rgb32f"] - ref["rgb32f"]).max() <= 1e-4, kw
+        assert out["counters"]["rays"] == ref["counters"]["rays"], kw
+        assert_rgb8_equal(out["rgb8"], ref["rgb8"], str(kw))
+    with pytest.raises(P.P3DError):
+        ds.render(hs.camera(), max_depth=depth, accel=accel, skybox=True, tree=True)      # features need tile / wavefront
+    ds.close()
+    hs2 = P.HostScene(scene_path(name)); hs2.set_resolution(*RES)
+    ds2 = P.DeviceScene.from_host(hs2)
+    with pytest.raises(P.P3DError):
+        ds2.render(hs2.camera(), skybox=True)                                               # no cube map given
+    ds2.close()
 
 
 def mean_and_var(frames):

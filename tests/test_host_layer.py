@@ -73,6 +73,12 @@ def test_host_grid_is_the_reference_grid(name):
     assert np.array_equal(counts, c_o.astype(np.uint32))
 
 
+def test_set_skybox_rejects_bad_arguments():
+    L = P.lib()
+    assert L.p3d_scene_set_skybox(None, None, None, None, None) == -1          # P3D_ERR_ARG, no GPU touched
+    assert b"NULL" in L.p3d_last_error()
+
+
 def test_host_grid_of_an_empty_and_of_a_flat_scene():
     """Grid::Build's cell-count formula on no primitives is (int)NaN -- undefined behaviour in the reference; the host
     builder answers with ONE empty cell.  A scene with no extent on one axis still gets the reference's grid (every

@@ -16,7 +16,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, REPO, scene_path
+from conftest import GOLDEN, REPO, scene_path, synthetic_cube_map
 from oracle import oracle_py as O
 from oracle import ref_py as R
 from oracle.ref_py import F, I
@@ -300,6 +300,25 @@ def test_baseline_configs_at_reduced_height_oracle_equals_reference():
         o = osc.render(max_depth=6, accel=2, spp=2, seed=12345, y0=240, y1=272)
         _same_frame(o, r, slice(240, 272))
         assert o["counters"]["rays"] == r["rays"]
+
+
+def test_skybox_lookup_bitexact_vs_reference_object_code():
+    """Scene::GetSkyboxColor (RT/scene.cpp:383-461): nothing in the reference calls it (SURVEY Q8), but its object code
+    exists and the oracle's restatement must equal it bit for bit -- 20 000 directions incl. the six axes, the face
+    diagonals (the `>` / `>=` tie rules of the face choice) and un-normalised ones, over a synthetic cube map whose six
+    faces differ in size and pixel width."""
+    faces = synthetic_cube_map()
+    rng = np.random.default_rng(17)
+    d = rng.standard_normal((20000, 3)).astype(np.float32)
+    d[:6] = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    d[6:12] = np.array([[1, 1, 0], [-1, 1, 0], [1, 0, 1], [0, 1, 1], [0, -1, 1], [1, 1, 1]], np.float32)
+    d[12:10000] /= np.linalg.norm(d[12:10000], axis=1, keepdims=True)
+    ref = R.skybox_colors(faces, d)
+    sc = O.Scene(scene_path("mount_low"))
+    sc.set_skybox(faces)
+    mine = np.stack([sc.skybox_color(v) for v in d])
+    assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
+    assert len(np.unique(ref, axis=0)) > 5000
 
 
 def test_single_raytracing_calls_bitexact():

@@ -20,7 +20,7 @@ FLAG_WAVEFRONT = 32
 FLAG_TILE_KERNEL = 64
 FLAG_DEVICE_SAMPLES = 128
 FLAG_PACKET_WALK = 256
-FEATURE_SOFT_SHADOW, FEATURE_FUZZY_REFLECTION = 1, 2
+FEATURE_SOFT_SHADOW, FEATURE_FUZZY_REFLECTION, FEATURE_SKYBOX = 1, 2, 4
 
 
 class P3DError(RuntimeError):
@@ -80,7 +80,7 @@ class SceneStats(C.Structure):
 
 # every symbol include/p3d_hip.h declares (tests check that the library exports them all)
 C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_scene_create",
-                 "p3d_scene_destroy", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
+                 "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
                  "p3d_get_counters", "p3d_get_profile", "p3d_last_schedule", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end", "p3d_deinterleave_frames",
                  "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_set_stamps", "p3d_debug_set_stamp_level",
                  "p3d_comm_unique_id", "p3d_comm_create", "p3d_comm_create_all", "p3d_comm_destroy", "p3d_comm_info",
@@ -120,6 +120,7 @@ def lib():
     L.p3d_device_count.argtypes = [C.POINTER(C.c_int)]
     L.p3d_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(BuildOpts), C.c_int, C.POINTER(C.c_void_p)]
     L.p3d_scene_destroy.argtypes = [C.c_void_p]
+    L.p3d_scene_set_skybox.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.p3d_scene_get_stats.argtypes = [C.c_void_p, C.POINTER(SceneStats)]
     L.p3d_local_rows.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.p3d_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.POINTER(Outputs)]
@@ -328,6 +329,15 @@ class DeviceScene:
         _check(lib().p3d_scene_get_stats(self.h, C.byref(s)), "p3d_scene_get_stats")
         return s.as_dict()
 
+    def set_skybox(self, faces):
+        """Six uint8 arrays [H, W, 3 or 4]: right, left, top, bottom, front, back; row 0 = bottom row (Scene::LoadSkybox)."""
+        faces = [np.ascontiguousarray(f, np.uint8) for f in faces]
+        ptrs = (C.c_void_p * 6)(*[f.ctypes.data for f in faces])
+        rx = (C.c_uint32 * 6)(*[f.shape[1] for f in faces])
+        ry = (C.c_uint32 * 6)(*[f.shape[0] for f in faces])
+        bpp = (C.c_uint32 * 6)(*[f.shape[2] for f in faces])
+        _check(lib().p3d_scene_set_skybox(self.h, ptrs, rx, ry, bpp), "p3d_scene_set_skybox")
+
     def set_stream(self, stream_ptr):
         _check(lib().p3d_set_stream(self.h, C.c_void_p(stream_ptr)), "p3d_set_stream")
 
@@ -369,20 +379,20 @@ class DeviceScene:
         _check(lib().p3d_get_counters(self.h, C.byref(c)), "p3d_get_counters")
         return c.as_dict()
 
-    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False, private_walk=False):
+    def _params(self, max_depth, accel, spp, samples, rank, world, row_block, counters, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False, private_walk=False, skybox=False):
         p = RenderParams()
         p.max_depth, p.accel, p.spp = int(max_depth), int(accel), int(spp)
         p.samples = samples.ctypes.data_as(C.POINTER(C.c_float)) if samples is not None else None
         if samples_ptr:                      # sample array already on the device (uploaded once by the caller)
             p.samples = C.cast(C.c_void_p(int(samples_ptr)), C.POINTER(C.c_float))
         p.row_block, p.rank, p.world = int(row_block), int(rank), int(world)
-        p.features = (FEATURE_SOFT_SHADOW if soft_shadow else 0) | (FEATURE_FUZZY_REFLECTION if fuzzy_reflection else 0)
+        p.features = (FEATURE_SOFT_SHADOW if soft_shadow else 0) | (FEATURE_FUZZY_REFLECTION if fuzzy_reflection else 0) | (FEATURE_SKYBOX if skybox else 0)
         p.seed = int(seed) & 0xFFFFFFFF
         p.flags = (FLAG_COUNTERS if counters else 0) | (FLAG_TREE_KERNEL if tree else 0) | (FLAG_NO_LDS_SCENE if no_lds else 0) | (FLAG_PROFILE if profile else 0) | (FLAG_WAVEFRONT if wavefront else 0) | (FLAG_TILE_KERNEL if tile else 0) | (FLAG_DEVICE_SAMPLES if samples_ptr else 0) | (FLAG_PACKET_WALK if packet else 0) | (FLAG_PRIVATE_WALK if private_walk else 0)
         return p
 
     def render(self, cam, max_depth=4, accel=ACCEL_BVH, spp=0, samples=None, rank=0, world=1, row_block=16,
-               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, packet=False, private_walk=False):
+               want_f32=True, want_hit=True, counters=False, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, packet=False, private_walk=False, skybox=False):
         """Render into host numpy arrays (rows: res_y for world==1, local_rows otherwise)."""
         rows = cam.res_y if world == 1 else local_rows(cam.res_y, row_block, world)
         rgb8 = np.zeros((rows, cam.res_x, 3), np.uint8)
@@ -390,7 +400,7 @@ class DeviceScene:
         hid = np.full((rows, cam.res_x), -2, np.int32) if want_hit else None
         if samples is not None:
             samples = np.ascontiguousarray(samples, np.float32)
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, 0, packet, private_walk)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, 0, packet, private_walk, skybox)
         o = Outputs(rgb8.ctypes.data, f32.ctypes.data if want_f32 else None,
                     hid.ctypes.data if want_hit else None, 0)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
@@ -400,10 +410,10 @@ class DeviceScene:
         return out
 
     def render_device(self, cam, rgb8_ptr=0, rgb32f_ptr=0, hit_ptr=0, max_depth=4, accel=ACCEL_BVH, spp=0,
-                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False, private_walk=False):
+                      samples=None, rank=0, world=1, row_block=16, counters=False, tree=False, no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False, samples_ptr=0, packet=False, private_walk=False, skybox=False):
         """Enqueue one frame into caller-owned DEVICE buffers (raw pointers); asynchronous.  samples_ptr: the
         spp > 0 sample array as a device pointer (uploaded once by the caller) instead of `samples`."""
-        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, samples_ptr, packet, private_walk)
+        p = self._params(max_depth, accel, spp, samples, rank, world, row_block, counters, tree, no_lds, profile, wavefront, soft_shadow, fuzzy_reflection, seed, tile, samples_ptr, packet, private_walk, skybox)
         o = Outputs(rgb8_ptr or None, rgb32f_ptr or None, hit_ptr or None, 1)
         _check(lib().p3d_render(self.h, C.byref(cam), C.byref(p), C.byref(o)), "p3d_render")
 

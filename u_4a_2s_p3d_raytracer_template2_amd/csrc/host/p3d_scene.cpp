@@ -436,6 +436,24 @@ int render_multi_gpu(const Scene::Flat& flat, const p3d_camera& cam, p3d_render_
 
 }  // namespace
 
+void Scene::SetSkybox(const uint8_t* const faces[6], const uint32_t res_x[6], const uint32_t res_y[6], const uint32_t bytes_per_pixel[6]) {
+    for (int i = 0; i < 6; i++) {
+        skybox_img[i].resX = res_x[i]; skybox_img[i].resY = res_y[i]; skybox_img[i].BPP = bytes_per_pixel[i];
+        skybox_img[i].img.assign(faces[i], faces[i] + (size_t)res_x[i] * res_y[i] * bytes_per_pixel[i]);
+    }
+}
+
+namespace {
+int upload_skybox(const Scene& scene, p3d_scene* dev) {
+    const uint8_t* faces[6]; uint32_t rx[6], ry[6], bpp[6];
+    for (int i = 0; i < 6; i++) {
+        const Scene::CubeFace& f = scene.GetSkyboxFace(i);
+        faces[i] = f.img.data(); rx[i] = f.resX; ry[i] = f.resY; bpp[i] = f.BPP;
+    }
+    return p3d_scene_set_skybox(dev, faces, rx, ry, bpp);
+}
+}  // namespace
+
 int renderScene(const Scene& scene, const RenderOptions& opt, bool want_colors, bool want_hit, RenderResult& out,
                 std::string* err) {
     auto bad = [&](int rc) { if (err) *err = p3d_last_error(); return rc; };
@@ -453,6 +471,11 @@ int renderScene(const Scene& scene, const RenderOptions& opt, bool want_colors, 
     prm.world = 1; prm.rank = 0; prm.row_block = 16;
     prm.flags = opt.counters ? P3D_FLAG_COUNTERS : 0;
     prm.features = (opt.SOFT_SHADOW ? P3D_FEATURE_SOFT_SHADOW : 0u) | (opt.FUZZY_REFLECTION ? P3D_FEATURE_FUZZY_REFLECTION : 0u);
+    if (opt.SKYBOX) {
+        if (!scene.HasSkybox()) { if (err) *err = "RenderOptions::SKYBOX without Scene::SetSkybox()"; return P3D_ERR_STATE; }
+        if (opt.gpus > 1) { if (err) *err = "the skybox switch is served on one GPU"; return P3D_ERR_ARG; }
+        prm.features |= P3D_FEATURE_SKYBOX;
+    }
     prm.seed = opt.seed;
     std::vector<float> samples;
     if (prm.spp > 0) {
@@ -467,6 +490,7 @@ int renderScene(const Scene& scene, const RenderOptions& opt, bool want_colors, 
     p3d_scene* dev = nullptr;
     int rc = p3d_scene_create(&flat.desc, nullptr, opt.device, &dev);
     if (rc) return bad(rc);
+    if (opt.SKYBOX && (rc = upload_skybox(scene, dev)) != 0) { p3d_scene_destroy(dev); return bad(rc); }
     size_t npx = (size_t)cam.res_x * cam.res_y;
     out.img_Data.assign(npx * 3, 0);
     if (want_colors) out.colors.assign(npx * 3, 0.0f);

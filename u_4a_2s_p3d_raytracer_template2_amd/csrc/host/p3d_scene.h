@@ -170,6 +170,12 @@ public:
     accelerator GetAccelStruct() const { return accel_struc_type; }
     void SetBackgroundColor(Color c) { bgColor = c; }
     void SetSkyBoxFlg(bool f) { SkyBoxFlg = f; }
+    // what Scene::LoadSkybox (RT/scene.cpp:333-381) fills from six image files through DevIL: here the caller brings the
+    // decoded faces (right, left, top, bottom, front, back; rows bottom-up; 3 or 4 bytes per pixel).  Copied.
+    void SetSkybox(const uint8_t* const faces[6], const uint32_t res_x[6], const uint32_t res_y[6], const uint32_t bytes_per_pixel[6]);
+    bool HasSkybox() const { return !skybox_img[0].img.empty(); }
+    struct CubeFace { std::vector<uint8_t> img; uint32_t resX = 0, resY = 0, BPP = 3; };
+    const CubeFace& GetSkyboxFace(int i) const { return skybox_img[i]; }
     void SetCamera(Camera* c) { delete camera; camera = c; }
     void SetAccelStruct(accelerator a) { accel_struc_type = a; }
     void SetSamplesPerPixel(unsigned int spp) { samples_per_pixel = spp; }
@@ -198,6 +204,7 @@ private:
     unsigned int samples_per_pixel = 0;
     accelerator accel_struc_type = NONE;
     bool SkyBoxFlg = false;
+    CubeFace skybox_img[6];                       // RT/scene.h:190-195
     std::string parse_err;
 };
 
@@ -218,6 +225,9 @@ struct RenderOptions {
     // DEPTH_OF_FIELD follow spp > 0 as in RT/main.cpp:943-944
     bool SOFT_SHADOW = false;
     bool FUZZY_REFLECTION = false;
+    // misses return Scene::GetSkyboxColor(ray) (RT/scene.cpp:383-461; never called by the reference) when the
+    // scene carries a cube map (Scene::SetSkybox): off by default, like in the reference's rayTracing()
+    bool SKYBOX = false;
 };
 struct RenderResult {
     std::vector<uint8_t> img_Data;   // RGB8, bottom row first (RT/main.cpp:76)

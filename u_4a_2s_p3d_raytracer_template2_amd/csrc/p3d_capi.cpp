@@ -119,6 +119,8 @@ struct p3d_scene {
     DevBuf<uint32_t> grid_cells, grid_items;
     GridHost grid_info; bool grid_ready = false;
     DevBuf<LightRec> soft_lights;          // 16 sub-lights per light, built on first use (SOFT_SHADOW, spp == 0)
+    DevBuf<uint8_t> sky;                   // cube map of P3D_FEATURE_SKYBOX: the six faces back to back
+    uint32_t sky_off[6] = {0, 0, 0, 0, 0, 0}, sky_w[6] = {0, 0, 0, 0, 0, 0}, sky_h[6] = {0, 0, 0, 0, 0, 0}, sky_bpp[6] = {0, 0, 0, 0, 0, 0};
     std::vector<LightRec> host_lights;
     size_t lds_scene_limit = kLdsSceneLimit;  // blobs up to this size are rendered from an LDS copy
     bool lds_capable = false;            // ... and then carry the f32 nodes the LDS walk reads
@@ -407,7 +409,7 @@ int p3d_scene_destroy(p3d_scene* s) {
     (void)hipSetDevice(s->device);
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     s->grid_cells.release(); s->grid_items.release();
-    s->blob.release(); s->qnodes.release(); s->planes.release(); s->plane_meta.release(); s->lights.release(); s->soft_lights.release();
+    s->blob.release(); s->qnodes.release(); s->planes.release(); s->plane_meta.release(); s->lights.release(); s->soft_lights.release(); s->sky.release();
     s->fb_rgb8.release(); s->fb_rgb32f.release(); s->fb_hit.release(); s->samples.release(); s->ray_tab.release();
     for (auto& w : s->ws) w.release();
     s->wf_planes.release(); s->tile_ws.release(); s->tile_ctrl.release();
@@ -424,6 +426,28 @@ int p3d_scene_destroy(p3d_scene* s) {
     for (auto& ev : s->ev_pick) if (ev) (void)hipEventDestroy(ev);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
     delete s;
+    return P3D_OK;
+}
+
+int p3d_scene_set_skybox(p3d_scene* s, const uint8_t* const faces[6], const uint32_t res_x[6], const uint32_t res_y[6],
+                         const uint32_t bytes_per_pixel[6]) {
+    if (!s || !faces || !res_x || !res_y || !bytes_per_pixel) return fail(P3D_ERR_ARG, "NULL argument");
+    std::vector<uint8_t> all;
+    uint32_t off[6];
+    for (int i = 0; i < 6; i++) {
+        if (!faces[i] || res_x[i] == 0 || res_y[i] == 0 || res_x[i] > 16384 || res_y[i] > 16384 || (bytes_per_pixel[i] != 3 && bytes_per_pixel[i] != 4))
+            return fail(P3D_ERR_ARG, "skybox faces must be 1..16384 pixels wide and high, 3 or 4 bytes per pixel");
+        const size_t bytes = (size_t)res_x[i] * res_y[i] * bytes_per_pixel[i];
+        if (all.size() + bytes > 0xFFFFFFF0ull) return fail(P3D_ERR_LIMIT, "skybox too large");
+        off[i] = (uint32_t)all.size();
+        all.insert(all.end(), faces[i], faces[i] + bytes);
+        all.resize((all.size() + 15) / 16 * 16);
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));              // (frames in flight may still read the old map)
+    s->sky.release();
+    HIP_TRY(s->sky.upload(all));
+    for (int i = 0; i < 6; i++) { s->sky_off[i] = off[i]; s->sky_w[i] = res_x[i]; s->sky_h[i] = res_y[i]; s->sky_bpp[i] = bytes_per_pixel[i]; }
     return P3D_OK;
 }
 
@@ -694,7 +718,13 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     P.wf_min_width = lds_scene ? 64 : 8;
 
     // distribution-ray-tracing switches (RT/main.cpp:40-45)
-    if (prm->features & ~(P3D_FEATURE_SOFT_SHADOW | P3D_FEATURE_FUZZY_REFLECTION)) return fail(P3D_ERR_ARG, "unknown feature bit");
+    if (prm->features & ~(P3D_FEATURE_SOFT_SHADOW | P3D_FEATURE_FUZZY_REFLECTION | P3D_FEATURE_SKYBOX)) return fail(P3D_ERR_ARG, "unknown feature bit");
+    if (prm->features & P3D_FEATURE_SKYBOX) {
+        if (!s->sky.p || s->sky_w[0] == 0) return fail(P3D_ERR_STATE, "P3D_FEATURE_SKYBOX needs p3d_scene_set_skybox() first");
+        P.features |= kFeatSky;
+        P.sky = s->sky.p;
+        for (int i = 0; i < 6; i++) { P.sky_off[i] = s->sky_off[i]; P.sky_w[i] = s->sky_w[i]; P.sky_h[i] = s->sky_h[i]; P.sky_bpp[i] = s->sky_bpp[i]; }
+    }
     if ((prm->features & P3D_FEATURE_SOFT_SHADOW) && prm->spp == 0 && s->n_lights) {
         // the 4x4 grid of RT/main.cpp:601-618 as 16 sub-lights per light, in the reference's loop order
         // and with its float arithmetic (cur_x / cur_y advance by repeated addition)
@@ -735,7 +765,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     const uint32_t forced = prm->flags & (P3D_FLAG_TREE_KERNEL | P3D_FLAG_WAVEFRONT | P3D_FLAG_TILE_KERNEL);
     if (forced & (forced - 1)) return fail(P3D_ERR_ARG, "at most one of P3D_FLAG_TREE_KERNEL / _WAVEFRONT / _TILE_KERNEL");
     if (stochastic && (prm->flags & P3D_FLAG_TREE_KERNEL))
-        return fail(P3D_ERR_ARG, "features with random draws need the tile or the wavefront schedule");
+        return fail(P3D_ERR_ARG, "features with random draws (and the skybox) need the tile or the wavefront schedule");
 
     {   // the workspace budget, capped by what the device has free (+ what this handle already holds)
         const int32_t bkey[4] = {cam->res_x, cam->res_y, prm->max_depth, prm->spp};

@@ -81,7 +81,7 @@ struct DeviceCounters {
 };
 
 constexpr uint32_t kWfShards = 64;           // queue shards of the wavefront schedule (LaunchParams::wf_shards); == the wave size
-constexpr uint32_t kFeatSoftJitter = 1u, kFeatFuzzy = 2u;                  // LaunchParams::features
+constexpr uint32_t kFeatSoftJitter = 1u, kFeatFuzzy = 2u, kFeatSky = 4u;   // LaunchParams::features
 constexpr uint32_t kShareDwords = 384;      // per-wave LDS of the work-sharing walk (p3d_traverse.h), behind the wave's stack slots
 
 // Everything a render launch needs, passed by value (lands in SGPRs / kernarg segment).
@@ -154,6 +154,8 @@ struct LaunchParams {
     // the random-stream key of every queued ray ([shard][cap] like the ray queues; nullptr when off)
     uint32_t features, seed;
     const uint32_t* wf_rng_in; uint32_t* wf_rng_out;
+    // cube map of P3D_FEATURE_SKYBOX (Scene::skybox_img, RT/scene.h:190-195): face i starts at sky + sky_off[i]
+    const uint8_t* sky; uint32_t sky_off[6], sky_w[6], sky_h[6], sky_bpp[6];
     unsigned long long* dbg_stamps;   // diagnostic: per (tile, wave) 8 x u64 timestamps, or nullptr
     int32_t dbg_stamp_level;          // which launch of a frame writes them: <= 1 the level-1 / tree / tile launch, l >= 2 the level-l launch
     // ---- uniform grid of GRID mode (accel 1; RT/grid.cpp): cell c holds grid_items[grid_cells[c] .. grid_cells[c+1])

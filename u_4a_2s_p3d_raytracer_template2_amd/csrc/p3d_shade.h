@@ -158,6 +158,35 @@ __device__ __forceinline__ V3 light_position(const LaunchParams& P, float4 lpos,
     return mk(lpos.x, lpos.y, lpos.z);
 }
 
+// Scene::GetSkyboxColor, RT/scene.cpp:383-461, same expressions in the same types: "double invMa = 1 / ma" is a float
+// division widened afterwards, s and t are formed in double and rounded once, the two clamping lines (:450,452) are
+// expression statements without effect, u8tofloat divides by 255.99f (RT/maths.h:120-123).  Bit-exact against the
+// reference's object code through the oracle (tests/test_oracle_vs_ref.py, tests/test_gpu_distribution.py).  A direction
+// with NaNs indexes outside the image in the reference (wild read); here it returns black.
+__device__ __forceinline__ V3 skybox_color(const LaunchParams& P, V3 c) {
+    float ma; int side;
+    if (fabsf(c.x) > fabsf(c.y)) { ma = fabsf(c.x); side = c.x >= 0.0f ? 1 : 0; }     // LEFT at X = +1, RIGHT at X = -1
+    else { ma = fabsf(c.y); side = c.y >= 0.0f ? 2 : 3; }                            // TOP / BOTTOM
+    if (fabsf(c.z) > ma) { ma = fabsf(c.z); side = c.z >= 0.0f ? 4 : 5; }            // FRONT / BACK
+    const float sc = side == 0 ? -c.z : side == 1 ? c.z : side == 5 ? c.x : -c.x;
+    const float tc = side == 2 ? -c.z : side == 3 ? c.z : c.y;
+    const double invMa = (double)fdiv(1.0f, ma);
+    const float s = (float)(((double)sc * invMa + 1.0) / 2.0);
+    const float t = (float)(((double)tc * invMa + 1.0) / 2.0);
+    const uint32_t width = P.sky_w[side], height = P.sky_h[side], bpp = P.sky_bpp[side];
+    const uint32_t xp = (uint32_t)(int)((float)(width - 1u) * s);
+    const uint32_t yp = (uint32_t)(int)((float)(height - 1u) * t);
+    if (!(xp < width && yp < height)) return mk(0.0f, 0.0f, 0.0f);
+    const uint8_t* px = P.sky + P.sky_off[side] + ((size_t)yp * width + xp) * bpp;
+    return mk(fdiv((float)px[0], 255.99f), fdiv((float)px[1], 255.99f), fdiv((float)px[2], 255.99f));
+}
+// what a ray that hits nothing returns: bgColor (RT/main.cpp:582), or the cube map with P3D_FEATURE_SKYBOX
+template <bool STOCH>
+__device__ __forceinline__ V3 miss_color(const LaunchParams& P, const Ray& ray) {
+    if (STOCH && (P.features & kFeatSky)) return skybox_color(P, ray.d);
+    return mk(P.bg[0], P.bg[1], P.bg[2]);
+}
+
 // colour returned by a node once its children returned refl_ret / refr_ret (zero when the
 // child was never traced): "color += reflection_color * KR * specColor + refraction_color *
 // (1 - KR)", RT/main.cpp:719, same association.
@@ -187,7 +216,7 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
 #endif
     const bool hit = live && h.ref != 0xFFFFFFFFu;
     if (__ballot(hit) == 0) {                     // whole wave missed (sky tiles): nothing to light
-        o.ret = mk(P.bg[0], P.bg[1], P.bg[2]);
+        o.ret = miss_color<STOCH>(P, ray);
         return o;
     }
     V3 hit_point = o.color, normal = o.color, precise = o.color;
@@ -226,7 +255,7 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
         }
     }
     if (!hit) {
-        o.ret = mk(P.bg[0], P.bg[1], P.bg[2]);
+        o.ret = miss_color<STOCH>(P, ray);
         return o;
     }
     Mtl M = load_material(sv, h.mat);
