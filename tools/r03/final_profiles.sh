@@ -35,3 +35,8 @@ kt synthetic_1000000 $R/tools/render_frames.py 1000000 default 30
 pmc synthetic_1000000 tools/render_frames.py 1000000 default 24
 ls -la $O | head -60
 echo done
+# frames in flight of config 2 (the default is 4)
+for f in 2 3 4 5 6 8; do
+  echo "frames_in_flight $f: $(python $R/bench.py --no-cpu-baseline --frames-in-flight $f --steps 30 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print(round(d['value']),'Mrays/s', round(d['ms_per_frame'],5),'ms/frame')")" >> $O/frames_in_flight.txt
+done
+cat $O/frames_in_flight.txt
