@@ -85,13 +85,17 @@ WORKLOADS = {
 HBM_SCENE_WORKLOADS = ("config3", "synthetic")      # scenes the kernels read from HBM / L2, not from an LDS copy
 
 
+# what the kernels are compiled from (host-side files do not make a profile stale)
+DEVICE_SOURCES = ("p3d_kernels.hip", "p3d_shade.h", "p3d_traverse.h", "p3d_device_math.h", "p3d_device_types.h", "bvh_device.hip",
+                  "pt_kernels.hip")
+
+
 def kernel_source_digest():
     """sha256 over the kernel sources: profiles taken from other kernels are flagged as stale."""
     h = hashlib.sha256()
     d = os.path.join(REPO, "u_4a_2s_p3d_raytracer_template2_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in DEVICE_SOURCES:
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

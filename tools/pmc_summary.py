@@ -51,9 +51,9 @@ def main():
     import hashlib
     hd = hashlib.sha256()
     cs_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "u_4a_2s_p3d_raytracer_template2_amd", "csrc")
-    for f in sorted(os.listdir(cs_dir)):
-        if f.endswith((".hip", ".h")):
-            hd.update(open(os.path.join(cs_dir, f), "rb").read())
+    for f in ("p3d_kernels.hip", "p3d_shade.h", "p3d_traverse.h", "p3d_device_math.h", "p3d_device_types.h", "bvh_device.hip",
+              "pt_kernels.hip"):                      # == bench.py: DEVICE_SOURCES
+        hd.update(open(os.path.join(cs_dir, f), "rb").read())
     res = {"_note": note, "kernel_source_digest": hd.hexdigest()[:16], "kernels": {}}
     for k, cs in sorted(acc.items()):
         e = {c: v[0] / v[1] for c, v in sorted(cs.items())}

@@ -296,7 +296,6 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     } else {
         build_bvh(F.build_prims, bo, nodes, refs, bs);
     }
-    if (const char* e = getenv("P3D_NODE_ORDER")) { if (!strcmp(e, "treelet")) reorder_treelets(nodes, 4); else if (!strcmp(e, "treelet8")) reorder_treelets(nodes, 8); }
     TypedLeaves TL;
     // Scenes small enough to be rendered from an LDS copy keep a record per leaf; the others name single-type leaves
     // in the reference itself (p3d_traverse.h: sv_leaf).  Upper bound of the blob with a record per leaf:

@@ -137,56 +137,6 @@ void type_leaves(std::vector<NodePair>& nodes, const std::vector<uint32_t>& refs
     F.spheres.swap(sph); F.sphere_meta.swap(sph_meta); F.tris.swap(tri); F.boxes.swap(box);
 }
 
-void reorder_treelets(std::vector<NodePair>& nodes, uint32_t k) {
-    const size_t n = nodes.size();
-    if (n < 3 || k < 2) return;
-    auto area = [](const NodePair& nd, int c) {
-        float lo[3], hi[3];
-        if (c == 0) { lo[0] = nd.lo0[0]; lo[1] = nd.lo0[1]; lo[2] = nd.lo0[2]; hi[0] = nd.hi0x; hi[1] = nd.hi0yz[0]; hi[2] = nd.hi0yz[1]; }
-        else { lo[0] = nd.lo1xy[0]; lo[1] = nd.lo1xy[1]; lo[2] = nd.lo1z; hi[0] = nd.hi1[0]; hi[1] = nd.hi1[1]; hi[2] = nd.hi1[2]; }
-        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-        return (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dx * dz + dy * dz : 0.0f;
-    };
-    std::vector<uint32_t> order; order.reserve(n);
-    std::vector<std::pair<float, int32_t>> frontier;          // (box area, node) of the current treelet's pending children
-    std::vector<int32_t> roots; roots.push_back(0);           // treelet roots still to lay out (a stack: depth first)
-    auto add_children = [&](int32_t node) {
-        const NodePair& nd = nodes[(size_t)node];
-        if (nd.child0 >= 0) frontier.push_back({area(nd, 0), nd.child0});
-        if (nd.child1 >= 0) frontier.push_back({area(nd, 1), nd.child1});
-    };
-    while (!roots.empty()) {
-        const int32_t r = roots.back(); roots.pop_back();
-        frontier.clear();
-        order.push_back((uint32_t)r);
-        add_children(r);
-        uint32_t in_treelet = 1;
-        while (in_treelet < k && !frontier.empty()) {
-            size_t best = 0;
-            for (size_t i = 1; i < frontier.size(); i++) if (frontier[i].first > frontier[best].first) best = i;
-            const int32_t c = frontier[best].second;
-            frontier.erase(frontier.begin() + (long)best);
-            order.push_back((uint32_t)c);
-            add_children(c);
-            in_treelet++;
-        }
-        // what is left starts treelets of its own; the largest box is laid out next
-        std::sort(frontier.begin(), frontier.end());
-        for (const auto& f : frontier) roots.push_back(f.second);
-    }
-    if (order.size() != n) return;                            // (unreachable nodes: leave the order alone)
-    std::vector<int32_t> where(n);
-    for (size_t i = 0; i < n; i++) where[order[i]] = (int32_t)i;
-    std::vector<NodePair> out(n);
-    for (size_t i = 0; i < n; i++) {
-        NodePair nd = nodes[order[i]];
-        if (nd.child0 >= 0) nd.child0 = where[(size_t)nd.child0];
-        if (nd.child1 >= 0) nd.child1 = where[(size_t)nd.child1];
-        out[i] = nd;
-    }
-    nodes.swap(out);
-}
-
 void quantise_nodes(const std::vector<NodePair>& nodes, QuantisedNodes& Q) {
     auto child_box = [](const NodePair& n, int c, float lo[3], float hi[3]) {
         if (c == 0) { lo[0] = n.lo0[0]; lo[1] = n.lo0[1]; lo[2] = n.lo0[2]; hi[0] = n.hi0x; hi[1] = n.hi0yz[0]; hi[2] = n.hi0yz[1]; }

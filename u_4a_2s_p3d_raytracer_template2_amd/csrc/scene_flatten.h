@@ -37,13 +37,8 @@ struct TypedLeaves {
 // direct: single-type leaves are named by their reference (kLeafTris / kLeafSpheres) instead of getting a LeafRec
 void type_leaves(std::vector<NodePair>& nodes, const std::vector<uint32_t>& refs, FlatScene& F, TypedLeaves& out, bool direct);
 
-// Node order.  The builders emit nodes depth first (a node, its first child's subtree, its second child's subtree): a
-// walk that descends into the first child stays in the cache line, one into the second child jumps.  reorder_treelets()
-// instead packs TREELETS of `k` nodes (k = 4: one 128-byte line of 32-byte QNodes): a treelet's root, then repeatedly the
-// pending child with the largest box (the likeliest to be visited), and lays the treelets themselves out depth first.
-// Only the numbering changes (the root stays node 0); must run before type_leaves().
-void reorder_treelets(std::vector<NodePair>& nodes, uint32_t k);
-
+// (Node order: the builders emit nodes depth first.  Treelets of 4 / 8 nodes per 128-byte line were built and measured in
+//  round 3 -- within 1 % on every scene, profiles/r03_exp03_sharing_wg_levers.txt -- and taken out again.)
 // 32-byte node pairs for scenes read from HBM (QNode): 16-bit plane codes on a grid over the boxes of all nodes,
 // plane = base + code * scale per axis.  Every coded box contains its f32 box with one code of margin on each side
 // (lo: floor - 1, hi: ceil + 1, evaluated in double against the f32 base / scale the device uses), so a slab test on the
