@@ -693,9 +693,16 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
             // is instantiated once per kernel.
             for (int l = 1; l <= D; l++) {
                 const uint32_t n = l == 1 ? kTilePx : T->n_rays[l];
-
-                for (uint32_t base = (uint32_t)wave * 64u; base < n; base += 256u) {
-                    const uint32_t i = base + lane;
+                // Whole rounds of 4 x 64 rays, then the remainder.  With the work-sharing walk (scenes read from HBM) the
+                // remainder is SPREAD over the four waves -- 40 queued rays are 10 per wave with 54 helper lanes each, not
+                // one wave of 40 beside three idle ones: the levels of a heavy tile are short queues of long walks.
+                constexpr bool kSpread = WALK == WALK_SHARED && !LDS;
+                const uint32_t full = (kSpread && l > 1) ? (n / 256u) * 256u : n, rem = n - full;     // (not spread: the plain loop)
+                const uint32_t per = (rem + 3u) / 4u;
+                for (uint32_t base = (uint32_t)wave * 64u; base < full || (base == full + (uint32_t)wave * 64u && rem > 0u); base += 256u) {
+                    const bool tail = base >= full;
+                    const uint32_t i = tail ? full + (uint32_t)wave * per + lane : base + lane;
+                    const bool in_batch = tail ? ((uint32_t)lane < per && i < n) : true;
                     bool valid; uint32_t link = (uint32_t)tid, rng = 0; float ior_1 = 1.0f;
                     Ray ray; ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(1.0f, 0.0f, 0.0f);
                     if (l == 1) {
@@ -703,7 +710,7 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
                         if (inside) ray = camera_ray(P, x, y, smp);
                         if (STOCH) rng = rng_mix(rng_mix(P.seed, (uint32_t)(y * P.res_x + x)), (uint32_t)smp);
                     } else {
-                        valid = i < n;
+                        valid = in_batch && i < n;
                         if (valid) {
                             const float4* rq = X.ray_slot(l, i);
                             const float4 a = rq[0], b = rq[1];
