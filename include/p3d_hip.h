@@ -337,6 +337,11 @@ int p3d_debug_intersect(int device, uint32_t n, const uint32_t* type, const floa
                         const float* origin, const float* dir, int32_t* hit, float* t,
                         float* normal);
 
+/* Unit-level probe of the one transcendental of the path: out[i] = the device's restatement of the host C library's
+ * powf(x[i], y[i]) (the Blinn-Phong exponent, RT/main.cpp:520; csrc/p3d_powf.h). Host arrays of n floats.
+ * The parity tests compare it bit for bit with the box's own libm. */
+int p3d_debug_powf(int device, uint32_t n, const float* x, const float* y, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ holds no output with these switches on (they are compile-time false there)."""
 import numpy as np
 import pytest
 
-from conftest import scene_path, synthetic_cube_map, assert_rgb8_equal
+from conftest import scene_path, synthetic_cube_map, assert_rgb8_equal, RGB_TOL
 from oracle import oracle_py as O
 import u_4a_2s_p3d_raytracer_template2_amd as P
 from u_4a_2s_p3d_raytracer_template2_amd import multigpu as MG
@@ -34,7 +34,7 @@ def test_soft_shadow_grid_matches_oracle(name, accel, depth):
     for kw in (dict(), dict(tree=True), dict(wavefront=True), dict(no_lds=True), dict(packet=True)):
         out = ds.render(hs.camera(), max_depth=depth, accel=accel, spp=0, soft_shadow=True, counters=True, **kw)
         assert np.array_equal(out["hit_id"], ref["hit_id"])
-        assert np.abs(out["rgb32f"] - ref["rgb32f"]).max() <= 1e-4
+        assert np.abs(out["rgb32f"] - ref["rgb32f"]).max() <= RGB_TOL
         assert out["counters"]["rays"] == ref["counters"]["rays"]
         d8 = np.abs(out["rgb8"].astype(int) - ref["rgb8"].astype(int))
         assert d8.max() <= 1 and (d8 != 0).mean() <= 1e-3
@@ -57,7 +57,7 @@ def test_skybox_frames_match_oracle(name, accel, depth):
     for kw in (dict(), dict(wavefront=True), dict(tile=True), dict(wavefront=True, no_lds=True), dict(tile=True, no_lds=True, private_walk=True)):
         out = ds.render(hs.camera(), max_depth=depth, accel=accel, spp=0, skybox=True, counters=True, **kw)
         assert np.array_equal(out["hit_id"], ref["hit_id"]), kw
-        assert np.abs(out["rgb32f"] - ref["rgb32f"]).max() <= 1e-4, kw
+        assert np.abs(out["rgb32f"] - ref["rgb32f"]).max() <= RGB_TOL, kw
         assert out["counters"]["rays"] == ref["counters"]["rays"], kw
         assert_rgb8_equal(out["rgb8"], ref["rgb8"], str(kw))
     with pytest.raises(P.P3DError):

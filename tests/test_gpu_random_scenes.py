@@ -4,7 +4,7 @@ oracle from the same file.  Also the degenerate inputs: no primitives, no lights
 import numpy as np
 import pytest
 
-from conftest import assert_rgb8_equal
+from conftest import assert_rgb8_equal, RGB_TOL
 from oracle import oracle_py as O
 import u_4a_2s_p3d_raytracer_template2_amd as P
 from scene_gen import write_scene
@@ -24,7 +24,7 @@ def check(path, accel, depth, **gpu_kw):
     assert np.array_equal(out["hit_id"], ref["hit_id"])
     fin = np.isfinite(ref["rgb32f"])
     assert np.array_equal(fin, np.isfinite(out["rgb32f"]))
-    assert np.abs(out["rgb32f"][fin] - ref["rgb32f"][fin]).max() <= 1e-4
+    assert np.abs(out["rgb32f"][fin] - ref["rgb32f"][fin]).max() <= RGB_TOL
     assert out["counters"]["rays"] == ref["counters"]["rays"]
     # (channels whose float colour is not finite quantise by an undefined float -> int conversion: left out)
     assert_rgb8_equal(np.where(fin, out["rgb8"], 0), np.where(fin, ref["rgb8"], 0), "random scene")
@@ -68,7 +68,7 @@ def test_deep_trees_fall_back_to_the_tree_kernel_when_the_queues_do_not_fit(tmp_
     ds.close()
     sc = O.Scene(path)
     ref = sc.render(max_depth=10, accel=2)
-    assert np.array_equal(a["hit_id"], ref["hit_id"]) and np.abs(a["rgb32f"] - ref["rgb32f"]).max() <= 1e-4
+    assert np.array_equal(a["hit_id"], ref["hit_id"]) and np.abs(a["rgb32f"] - ref["rgb32f"]).max() <= RGB_TOL
 
 
 def test_rays_with_a_zero_direction_component(tmp_path):

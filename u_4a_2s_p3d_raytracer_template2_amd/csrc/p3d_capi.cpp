@@ -17,6 +17,8 @@
 #include "grid_builder.h"
 #include "p3d_device_types.h"
 #include "scene_flatten.h"
+#define P3D_POWF_TABLES_ONLY
+#include "p3d_powf.h"
 
 namespace p3d {
 size_t tree_kernel_lds_bytes(const LaunchParams& P, bool lds);
@@ -42,6 +44,7 @@ hipError_t build_lbvh_device(const std::vector<BuildPrim>& prims, const BvhOptio
                              uint32_t* d_refs, BvhStats& stats, hipStream_t stream);
 hipError_t sort_tiles_by_cost(const uint32_t* cost, uint32_t* cost_sorted, uint32_t* iota, uint32_t* order, uint32_t n,
                               void* temp, size_t& temp_bytes, hipStream_t stream);
+hipError_t launch_debug_powf(uint32_t n, const float* x, const float* y, float* out, hipStream_t stream);
 hipError_t launch_debug_intersect(uint32_t n, const uint32_t* type, const float* prim12, const float* origin,
                                   const float* dir, int32_t* hit, float* t, float* normal, hipStream_t stream);
 }  // namespace p3d
@@ -106,7 +109,7 @@ struct RawBuf {
 struct p3d_scene {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    DevBuf<uint32_t> blob;              // leaf records | spheres | sphere meta | tris | boxes | materials [| f32 nodes: LDS scenes]
+    DevBuf<uint32_t> blob;              // powf tables (32 quads) | leaf records | spheres | sphere meta | tris | boxes | materials [| f32 nodes: LDS scenes]
     DevBuf<QNode> qnodes;               // 32-byte node pairs: what kernels that read the scene from HBM walk
     float q_scale[3] = {1, 1, 1}, q_base[3] = {0, 0, 0};
     uint32_t blob_quads = 0;
@@ -300,7 +303,7 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
     // Scenes small enough to be rendered from an LDS copy keep a record per leaf; the others name single-type leaves
     // in the reference itself (p3d_traverse.h: sv_leaf).  Upper bound of the blob with a record per leaf:
     const size_t blob_bound = nodes.size() * (sizeof(NodePair) + 2 * sizeof(LeafRec)) + 16 + F.spheres.size() * (sizeof(SphereRec) + sizeof(PrimMeta)) +
-                              F.tris.size() * sizeof(TriRec) + F.boxes.size() * sizeof(BoxRec) + F.materials.size() * sizeof(MaterialRec) + 8 * 16;
+                              F.tris.size() * sizeof(TriRec) + F.boxes.size() * sizeof(BoxRec) + F.materials.size() * sizeof(MaterialRec) + 8 * 16 + P3D_POW_TAB_BYTES;
     const bool small_scene = blob_bound <= kLdsSceneLimit;
     type_leaves(nodes, refs, F, TL, !small_scene);
     if (TL.overflow) return fail(P3D_ERR_LIMIT, "too many mixed-type leaves");
@@ -348,6 +351,17 @@ int p3d_scene_create(const p3d_scene_desc* d, const p3d_build_opts* opts, int de
             if (bytes) memcpy(blob.data() + at, data, bytes);
             return off;
         };
+        {   // powf's tables lead the blob: kernels that render from an LDS copy of it read them at LDS address 0 (p3d_powf.h)
+            static const double log2_tab[16][2] = P3D_POW_LOG2_TAB_INIT;
+            static const uint64_t exp2_tab[32] = P3D_POW_EXP2_TAB_INIT;
+            static const double coefs[10] = P3D_POW_COEF_INIT;
+            static_assert(sizeof log2_tab + sizeof exp2_tab + sizeof coefs == P3D_POW_TAB_BYTES, "powf table layout");
+            unsigned char tab[P3D_POW_TAB_BYTES];
+            memcpy(tab, log2_tab, sizeof log2_tab);
+            memcpy(tab + sizeof log2_tab, exp2_tab, sizeof exp2_tab);
+            memcpy(tab + sizeof log2_tab + sizeof exp2_tab, coefs, sizeof coefs);
+            if (section(tab, sizeof tab) != 0u) return bail(hipErrorUnknown, "scene blob layout");
+        }
         s->off_leaves = section(TL.leaves.data(), TL.leaves.size() * sizeof(LeafRec));
         s->off_spheres = section(spheres.data(), spheres.size() * sizeof(SphereRec));
         s->off_sphere_meta = section(sphere_meta.data(), sphere_meta.size() * sizeof(PrimMeta));
@@ -1211,6 +1225,24 @@ int p3d_debug_intersect(int device, uint32_t n, const uint32_t* type, const floa
 #undef DBG_TRY
     cleanup();
     return rc;
+}
+
+int p3d_debug_powf(int device, uint32_t n, const float* x, const float* y, float* out) {
+    if (!x || !y || !out) return fail(P3D_ERR_ARG, "NULL argument");
+    if (n == 0) return P3D_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(P3D_ERR_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    float* d = nullptr;                                   // x | y | out
+    HIP_TRY(hipMalloc((void**)&d, (size_t)n * 12));
+    hipError_t e = hipMemcpy(d, x, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, y, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_debug_powf(n, d, d + n, d + 2 * (size_t)n, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(P3D_ERR_HIP, std::string("p3d_debug_powf: ") + hipGetErrorString(e));
+    return P3D_OK;
 }
 
 }  // extern "C"

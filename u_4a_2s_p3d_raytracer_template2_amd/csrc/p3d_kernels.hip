@@ -243,7 +243,16 @@ template <> struct View<false> {
         for (int a = 0; a < 3; a++) { g.qs[a] = P.q_scale[a]; g.qb[a] = P.q_base[a]; }
         return g;
     }
-    static __device__ __forceinline__ uint32_t scene_dwords(const LaunchParams&) { return 0; }
+    // kernels that shade: powf's tables and coefficients (the head of every blob) go to LDS address 0 (p3d_powf.h);
+    // one barrier, reached by every thread of the workgroup (call before any divergent exit)
+    static __device__ __forceinline__ GlobalScene make_shading(const LaunchParams& P) {
+        const float4* src = reinterpret_cast<const float4*>(P.blob);
+        float4* dst = reinterpret_cast<float4*>(p3d_lds);
+        if (threadIdx.x < P3D_POW_TAB_BYTES / 16u) dst[threadIdx.x] = src[threadIdx.x];
+        __syncthreads();
+        return make(P);
+    }
+    static __device__ __forceinline__ uint32_t scene_dwords(const LaunchParams&) { return P3D_POW_TAB_BYTES / 4u; }
 };
 template <> struct View<true> {
     typedef LdsScene type;
@@ -256,6 +265,7 @@ template <> struct View<true> {
         l.o = SceneOffsets{P.off_nodes, P.off_leaves, P.off_spheres, P.off_sphere_meta, P.off_tris, P.off_tri_normals, P.off_boxes, P.off_mats, P.tri_quads};
         return l;
     }
+    static __device__ __forceinline__ LdsScene make_shading(const LaunchParams& P) { return make(P); }
     static __device__ __forceinline__ uint32_t scene_dwords(const LaunchParams& P) { return P.blob_quads * 4; }
 };
 
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_primary_kernel
         uint32_t* other = P.wf_alt + (size_t)((1u - par) * 2u) * kWfShards;
         for (uint32_t i = threadIdx.x; i < 2u * kWfShards; i += blockDim.x) other[i] = 0u;
     }
-    const typename View<LDS>::type sv = View<LDS>::make(P);
+    const typename View<LDS>::type sv = View<LDS>::make_shading(P);
     int x, y, row, tile;
     const bool valid = tile_pixel<!LDS>(P, x, y, row, &tile);
     if (__ballot(valid) == 0) return;
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
         for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
         const uint32_t total = __shfl(incl, 63);
         if (((blockIdx.x * blockDim.x) >> 6) >= total) return;      // workgroup-uniform, before the scene copy's barrier
-        const typename View<LDS>::type sv = View<LDS>::make(P);
+        const typename View<LDS>::type sv = View<LDS>::make_shading(P);
         const TravCtx tc = wave_stack<LDS>(P, 0);
         Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
         uint32_t n_batches = 0;
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void wf_secondary_kern
         }
         if (!any) return;
     }
-    const typename View<LDS>::type sv = View<LDS>::make(P);
+    const typename View<LDS>::type sv = View<LDS>::make_shading(P);
     const Shard sh = shard_of(P, wave_id % S, par);
     const TravCtx tc = wave_stack<LDS>(P, 0);
     Ctr ctr = {0, 0, 0, 0, 0, 0, 0};
@@ -643,7 +653,7 @@ __device__ __forceinline__ void tile_emit(const LaunchParams& P, const TileCtx& 
 
 template <bool COUNT, bool LDS, int WALK, int OCC, bool STOCH = false>
 __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchParams P) {
-    const typename View<LDS>::type sv = View<LDS>::make(P);
+    const typename View<LDS>::type sv = View<LDS>::make_shading(P);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const TravCtx tc = wave_stack<LDS>(P, 0);
     TileCtx X;
@@ -918,7 +928,7 @@ __device__ __forceinline__ void trace_trees_shared(const LaunchParams& P, const 
 // PRIV = dwords of private memory for the frames (12 per level below the first), 0 = frames in LDS
 template <bool COUNT, bool LDS, int OCC, bool GRID = false, int PRIV = 0, bool SHARED = false>
 __global__ __launch_bounds__(LDS ? 256 : 64) P3D_OCC(OCC) void whitted_tree_kernel(const LaunchParams P) {
-    const typename View<LDS>::type sv = View<LDS>::make(P);
+    const typename View<LDS>::type sv = View<LDS>::make_shading(P);
     const int lane = threadIdx.x & 63;
     int x, y, row, tile;
     const bool in_image = tile_pixel<!LDS>(P, x, y, row, &tile);
@@ -1042,7 +1052,7 @@ __global__ void debug_intersect_kernel(uint32_t n, const uint32_t* type, const f
 }
 
 // ------------------------------------------------------------------ launchers (host)
-static size_t scene_lds_bytes(const LaunchParams& P, bool lds) { return lds ? (size_t)P.blob_quads * 16 : 0; }
+static size_t scene_lds_bytes(const LaunchParams& P, bool lds) { return lds ? (size_t)P.blob_quads * 16 : (size_t)P3D_POW_TAB_BYTES; }
 // frames of the tree kernel: private memory for scenes read from HBM up to depth 8, LDS otherwise
 static int tree_private_dwords(const LaunchParams& P, bool lds) {
     if (lds || P.accel == 1) return 0;
@@ -1238,6 +1248,15 @@ hipError_t launch_deinterleave(const void* gathered, void* frames, int res_x, in
     else
         hipLaunchKernelGGL(deinterleave_kernel<uint8_t>, grid, dim3(256), 0, stream, (const uint8_t*)gathered, (uint8_t*)frames,
                            row_bytes, res_y, row_block, world, rank_stride, in_stride, out_stride);
+    return hipGetLastError();
+}
+
+__global__ void debug_powf_kernel(uint32_t n, const float* x, const float* y, float* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = p3d_powf(x[i], y[i]);
+}
+hipError_t launch_debug_powf(uint32_t n, const float* x, const float* y, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(debug_powf_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, x, y, out);
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 #define P3D_SHADE_H
 
 #include "p3d_traverse.h"
+#include "p3d_powf.h"
 
 namespace p3d {
 
@@ -111,7 +112,8 @@ __device__ __forceinline__ void light_term(V3 L, V3 lcol, V3& color, const Mtl& 
         color = add(color, mul(diff, M.kd));
         return;
     }
-    V3 spec = mul(cmul(lcol, M.spec), powf(max2, M.shine));
+    // the host libm's powf, bit for bit (p3d_powf.h); max2 is +0 or positive
+    V3 spec = mul(cmul(lcol, M.spec), p3d_powf_nonneg(max2, M.shine, PowTabLds()));
     color = add(color, add(mul(diff, M.kd), mul(mul(spec, M.ks), 0.4f)));
 }
 
