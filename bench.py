@@ -453,6 +453,8 @@ def main():
     ap.add_argument("--prims", type=int, default=1000000, help="synthetic workload: number of primitives")
     ap.add_argument("--schedule", choices=["default", "wavefront", "tree", "tile"], default="default",
                     help="force a kernel schedule (default: the library's measured choice)")
+    ap.add_argument("--tune", choices=["on", "off"], default="on",
+                    help="scenes read from HBM: let the library rank its schedules with the bench's frames in flight (p3d_tune_schedule)")
     ap.add_argument("--spp", type=int, default=256, help="pathtracer workload: samples (frames) per step")
     args = ap.parse_args()
 
@@ -614,6 +616,16 @@ def main():
             h.render_device(cam, rgb8_ptr=tile_sets[0][0].data_ptr(), **sched, **kw)
         h.sync()
     torch.cuda.synchronize()
+    # ... and then has the library rank the same candidates the way the timed region runs them: all F handles in flight
+    # (p3d_tune_schedule; one frame at a time the dragon's ranking is tile 0.84 / tree 0.90 ms, with four in flight
+    # tree 0.59 / tile 0.63 ms per frame: profiles/r03_exp15_25_libm_powf.txt)
+    tuned = None
+    if not sched and args.workload in HBM_SCENE_WORKLOADS and F > 1 and args.tune == "on":
+        best, ms6 = P.tune_schedule(handles, cam, [tile_sets[0][k % B].data_ptr() for k in range(F)], frames=3, **kw)
+        if best >= 0:
+            tuned = {"best": ["wavefront", "tree", "tile"][best % 3] + (" / shared walks" if best < 3 else " / private walks"),
+                     "ms_per_frame_in_flight": {("%s / %s" % (["wavefront", "tree", "tile"][k % 3], "shared" if k < 3 else "private")): round(v, 4)
+                                                for k, v in enumerate(ms6) if v >= 0}}
     graphs = None
     # eager launches by default: replaying a step as one captured graph measured SLOWER on a rank's share of a tiled
     # frame (tools/shard_probe.py, 1/8 of config 2: 0.025-0.029 ms/frame eager, 0.033-0.035 as a graph; whole frame:
@@ -730,7 +742,9 @@ def main():
             "data": data,
             "config": {"workload": ("SURVEY 8d scaling scene, %d primitives, 1920x1080 depth 4 BVH" % args.prims) if synthetic else wl["name"],
                        "frames_per_step": B, "frames_in_flight": F, "hip_graph": graphs is not None,
-                       "schedule": chosen + (" (forced)" if sched else " (library default)"),
+                       "schedule": chosen + (" (forced)" if sched else
+                                             (" (library: measured with %d frames in flight, p3d_tune_schedule)" % F) if tuned else " (library default)"),
+                       "schedule_tuning": tuned,
                        "gather": None if world == 1 else
                                  ("FALLBACK gloo through host memory: " + ("rehearsal mode" if rehearsal else "p3d_comm_create failed (%s)" % comm_error))
                                  if host_gather else

@@ -257,6 +257,19 @@ int p3d_get_profile(p3d_scene* scene, float* frame_ms, float* kernel_ms);
  * first render. */
 int p3d_last_schedule(p3d_scene* scene, int32_t* schedule);
 
+/* Schedule choice under the caller's load. For scenes read from HBM the library measures its kernel schedules (and whether
+ * the lanes of a wave share their BVH walks) on the first frames of a configuration, ONE frame at a time, and keeps the
+ * fastest (p3d_last_schedule). A caller that keeps several frames in flight -- n scene handles of the same scene, one
+ * stream each -- can have the same candidates measured the way it runs them: every candidate renders `frames` frames
+ * (<= 0: 3) on all n handles at once, timed as a batch on the host clock, and all handles adopt the candidate with the
+ * shortest time per frame for this configuration (resolution, depth, accel, spp, flags, features). outs[i] is where
+ * handle i renders (device memory: the frames are real frames; results never depend on the choice). Synchronous.
+ * ms_per_frame (6 floats or NULL): wavefront / tree / tile with shared walks, then with private walks; -1 = not
+ * available. best (or NULL): the adopted candidate's index, -1 when this configuration's schedule is set by rule
+ * (scenes served from LDS) or by a P3D_FLAG_* of params -- then nothing is measured. Not while capturing a graph. */
+int p3d_tune_schedule(p3d_scene** scenes, int32_t n, const p3d_camera* cam, const p3d_render_params* params,
+                      const p3d_outputs* outs, int32_t frames, float* ms_per_frame, int32_t* best);
+
 /* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the
  * scene's own stream. */
 int p3d_set_stream(p3d_scene* scene, void* hip_stream);

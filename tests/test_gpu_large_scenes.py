@@ -69,6 +69,45 @@ def test_schedule_pick_is_measured_and_invisible():
     ds.close()
 
 
+def test_tuned_schedule_choice_with_frames_in_flight():
+    """p3d_tune_schedule: the same candidates, measured with several handles in flight; every handle adopts the winner for
+    that configuration and the frames stay what they were."""
+    import torch
+    hs = P.HostScene(scene_path("dragon"))
+    W, H = 256, 144
+    hs.set_resolution(W, H)
+    cam = hs.camera()
+    handles = [P.DeviceScene.from_host(hs) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in handles]
+    for h, st in zip(handles, streams):
+        h.set_stream(st.cuda_stream)
+    bufs = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in handles]
+    ref = handles[0].render(cam, max_depth=4, accel=2)
+    best, ms = P.tune_schedule(handles, cam, [b.data_ptr() for b in bufs], frames=2, max_depth=4, accel=2)
+    assert 0 <= best < 6 and len(ms) == 6 and all(v > 0 for v in ms)         # the dragon can run all six
+    assert ms[best] == min(ms)
+    names = ["wavefront", "tree", "tile"]
+    for h, b in zip(handles, bufs):
+        b.zero_()
+        h.render_device(cam, rgb8_ptr=b.data_ptr(), max_depth=4, accel=2)
+        h.sync()
+        assert h.last_schedule() == names[best % 3]                          # adopted, no fresh measurement
+        assert np.array_equal(b.cpu().numpy(), ref["rgb8"])
+    # private walks demanded: three candidates, the shared ones are not measured
+    best, ms = P.tune_schedule(handles, cam, [b.data_ptr() for b in bufs], frames=1, max_depth=4, accel=2, private_walk=True)
+    assert 0 <= best < 3 and all(v > 0 for v in ms[:3]) and all(v < 0 for v in ms[3:])
+    # a forced schedule or a scene served from LDS leaves nothing to choose
+    best, ms = P.tune_schedule(handles, cam, [b.data_ptr() for b in bufs], frames=1, max_depth=4, accel=2, tree=True)
+    assert best == -1 and all(v < 0 for v in ms)
+    for h in handles:
+        h.close()
+    hs2 = P.HostScene(scene_path("mount_low")); hs2.set_resolution(W, H)
+    ds2 = P.DeviceScene.from_host(hs2)
+    best, ms = P.tune_schedule([ds2], hs2.camera(), [bufs[0].data_ptr()], frames=1, max_depth=4, accel=2)
+    assert best == -1
+    ds2.close()
+
+
 def test_device_built_bvh_gives_the_same_frames(tmp_path):
     """p3d_build_opts.builder = 1: linear BVH built on the GPU.  Any conservative tree gives the same image."""
     n, res = 20000, (96, 54)

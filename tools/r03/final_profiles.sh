@@ -27,12 +27,20 @@ pmc() {  # pmc TAG script args...
 kt config2 $R/bench.py --no-cpu-baseline --frames-in-flight 1 --steps 10 --warmup 3
 kt config2_default $R/bench.py --no-cpu-baseline
 pmc config2 bench.py --no-cpu-baseline --frames-in-flight 1 --steps 2 --warmup 2
-kt config3 $R/tools/render_frames.py dragon default 40
-pmc config3 tools/render_frames.py dragon default 30
+# the profile of a scene read from HBM shows the schedule (and walk) the bench line of this run adopted (p3d_tune_schedule)
+sched_of() { python3 -c "
+import json,sys
+c=json.load(open(sys.argv[1]))['config']; t=c.get('schedule_tuning')
+s=c['schedule'].split()[0]
+print(s + ('_private' if t and 'private' in t['best'] else '') if t else 'default')" $1; }
+S3=$(sched_of $O/bench_config3.json); echo "config3 profiled as: $S3"
+kt config3 $R/tools/render_frames.py dragon $S3 40
+pmc config3 tools/render_frames.py dragon $S3 30
 kt config4 $R/tools/config4.py
 pmc config4 tools/config4.py
-kt synthetic_1000000 $R/tools/render_frames.py 1000000 default 30
-pmc synthetic_1000000 tools/render_frames.py 1000000 default 24
+S6=$(sched_of $O/bench_synthetic_1e6.json); echo "1e6 primitives profiled as: $S6"
+kt synthetic_1000000 $R/tools/render_frames.py 1000000 $S6 30
+pmc synthetic_1000000 tools/render_frames.py 1000000 $S6 24
 ls -la $O | head -60
 echo done
 # frames in flight of config 2 (the default is 4)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Render a few frames of one scene (name of a golden .p3f, or N = primitives of the synthetic scaling
-scene) with one schedule: wavefront | tree | tile | default.  For rocprofv3 runs.
+scene) with one schedule: wavefront | tree | tile | default (| X_private: forced with private walks).  For rocprofv3 runs.
 usage: render_frames.py SCENE SCHEDULE [FRAMES [W H [DEPTH]]]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +22,9 @@ else:
     ds, cam = P.DeviceScene.from_host(hs), hs.camera()
 buf = torch.zeros((res[1] + 16, res[0], 3), dtype=torch.uint8, device="cuda")
 kw = {"wavefront": dict(wavefront=True), "tree": dict(tree=True), "tile": dict(tile=True), "default": {},
-      "wavefront_packet": dict(wavefront=True, packet=True)}[sched]
+      "wavefront_packet": dict(wavefront=True, packet=True),
+      "wavefront_private": dict(wavefront=True, private_walk=True), "tree_private": dict(tree=True, private_walk=True),
+      "tile_private": dict(tile=True, private_walk=True)}[sched]
 for _ in range(n):
     ds.render_device(cam, rgb8_ptr=buf.data_ptr(), max_depth=depth, **kw)
 ds.sync()

@@ -6,8 +6,8 @@ fallback: importing `api` without a built libp3d_hip.so raises.
 """
 from .api import (PathTracer, pt_debug_hash, ACCEL_BVH, ACCEL_GRID, ACCEL_NONE, Counters, DeviceScene, HostScene, P3DError,
                   build_native, debug_intersect, debug_powf, device_count, host_bvh, lib, local_rows, Comm, comm_unique_id,
-                  gather_all)
+                  gather_all, tune_schedule)
 
 __all__ = ["PathTracer", "pt_debug_hash", "ACCEL_BVH", "ACCEL_GRID", "ACCEL_NONE", "Counters", "DeviceScene", "HostScene", "P3DError",
            "build_native", "debug_intersect", "debug_powf", "device_count", "host_bvh", "lib", "local_rows", "Comm", "comm_unique_id",
-           "gather_all"]
+           "gather_all", "tune_schedule"]

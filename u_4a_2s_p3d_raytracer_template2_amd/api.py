@@ -82,7 +82,7 @@ class SceneStats(C.Structure):
 C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_scene_create",
                  "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
                  "p3d_get_counters", "p3d_get_profile", "p3d_last_schedule", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end", "p3d_deinterleave_frames",
-                 "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_powf", "p3d_debug_set_stamps", "p3d_debug_set_stamp_level",
+                 "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_powf", "p3d_tune_schedule", "p3d_debug_set_stamps", "p3d_debug_set_stamp_level",
                  "p3d_comm_unique_id", "p3d_comm_create", "p3d_comm_create_all", "p3d_comm_destroy", "p3d_comm_info",
                  "p3d_gather", "p3d_gather_all", "p3d_device_alloc", "p3d_device_free", "p3d_upload", "p3d_download"]
 
@@ -151,6 +151,7 @@ def lib():
     L.p3d_pt_reduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.p3d_debug_intersect.argtypes = [C.c_int, C.c_uint32] + [C.c_void_p] * 7
     L.p3d_debug_powf.argtypes = [C.c_int, C.c_uint32] + [C.c_void_p] * 3
+    L.p3d_tune_schedule.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     # host shim
     L.p3dh_scene_load.restype = C.c_void_p
     L.p3dh_scene_load.argtypes = [C.c_char_p]
@@ -430,6 +431,27 @@ class DeviceScene:
     def deinterleave(self, gathered_ptr, frame_ptr, res_x, res_y, row_block, world, bpp, rank_stride_bytes=0):
         _check(lib().p3d_deinterleave(self.h, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), res_x, res_y,
                                       row_block, world, bpp, int(rank_stride_bytes)), "p3d_deinterleave")
+
+
+def tune_schedule(handles, cam, rgb8_ptrs, frames=3, **kw):
+    """p3d_tune_schedule over DeviceScene handles (one stream each): measure the schedule candidates with all of them in
+    flight and adopt the fastest.  rgb8_ptrs: one device buffer per handle.  kw as for render_device.
+    -> (best, [ms per frame of the six candidates]); best = -1: nothing to choose (rule or flag)."""
+    n = len(handles)
+    assert n >= 1 and len(rgb8_ptrs) == n
+    k = dict(max_depth=4, accel=ACCEL_BVH, spp=0, samples=None, rank=0, world=1, row_block=16, counters=False, tree=False,
+             no_lds=False, profile=False, wavefront=False, soft_shadow=False, fuzzy_reflection=False, seed=0, tile=False,
+             samples_ptr=0, packet=False, private_walk=False, skybox=False)
+    k.update(kw)
+    p = handles[0]._params(k["max_depth"], k["accel"], k["spp"], k["samples"], k["rank"], k["world"], k["row_block"], k["counters"],
+                           k["tree"], k["no_lds"], k["profile"], k["wavefront"], k["soft_shadow"], k["fuzzy_reflection"], k["seed"],
+                           k["tile"], k["samples_ptr"], k["packet"], k["private_walk"], k["skybox"])
+    hs = (C.c_void_p * n)(*[h.h.value if isinstance(h.h, C.c_void_p) else h.h for h in handles])
+    outs = (Outputs * n)(*[Outputs(int(q) or None, None, None, 1) for q in rgb8_ptrs])
+    ms = (C.c_float * 6)()
+    best = C.c_int32(-1)
+    _check(lib().p3d_tune_schedule(hs, n, C.byref(cam), C.byref(p), outs, int(frames), ms, C.byref(best)), "p3d_tune_schedule")
+    return int(best.value), [float(v) for v in ms]
 
 
 COMM_ID_BYTES = 128

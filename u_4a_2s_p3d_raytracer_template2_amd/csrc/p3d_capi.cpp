@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -195,6 +196,10 @@ struct p3d_scene {
         float ms[6] = {-1.0f, -1.0f, -1.0f, -1.0f, -1.0f, -1.0f};     // wavefront, tree, tile with shared walks; the same with private walks
         int pending = -1, step = 0, best = 2;
     } pick;
+    // p3d_tune_schedule(): a candidate forced for the frames it times, the winner to adopt at the next frame, and what the
+    // most recent frame's measured choice had to choose from (0: the choice is made by rule or by a flag)
+    int tune_force = -1, tune_commit = -1, tune_candidates = 0;
+    uint32_t tune_avail = 0;
     hipEvent_t ev_pick[2] = {nullptr, nullptr};
     bool profile_valid = false;
     bool timer_open = false;
@@ -848,6 +853,7 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
     if (frame_streams > 1) band_tile_rows = std::min<size_t>(band_tile_rows, ((size_t)P.tiles_y + frame_streams - 1) / frame_streams);
     const bool wavefront_ok = band_tile_rows > 0;
 
+    s->tune_candidates = 0;
     int sched = SCHED_TILE;
     int measuring = -1;                 // schedule this frame is timed as, for the pick below
     int measured_cand = -1;             // ... and the pick's candidate (schedule x shared / private walks) it counts for
@@ -877,7 +883,18 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         const int32_t key[8] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world,
                                 (int32_t)((prm->flags & (P3D_FLAG_NO_LDS_SCENE | P3D_FLAG_PACKET_WALK | P3D_FLAG_COUNTERS | P3D_FLAG_PRIVATE_WALK)) | (prm->features << 9))};
         int cand = -1;
-        if (cap != hipStreamCaptureStatusNone) {
+        s->tune_candidates = NC;
+        s->tune_avail = 0;
+        for (int k = 0; k < NC; k++) if (avail_s[k % NS]) s->tune_avail |= 1u << k;
+        if (s->tune_commit >= 0) {              // p3d_tune_schedule() measured this configuration under the caller's load
+            memcpy(pk.key, key, sizeof key);
+            pk.best = s->tune_commit < NC ? s->tune_commit : SCHED_TILE;
+            pk.step = 2 * NC + 1; pk.pending = -1;
+            s->tune_commit = -1;
+        }
+        if (s->tune_force >= 0) {
+            if (s->tune_force < NC) cand = s->tune_force;
+        } else if (cap != hipStreamCaptureStatusNone) {
             // events cannot be read while the stream is being captured: use what is known, measure nothing
             if (memcmp(key, pk.key, sizeof key) == 0 && pk.step >= 2 * NC) cand = pk.best;
         } else {
@@ -1225,6 +1242,49 @@ int p3d_debug_intersect(int device, uint32_t n, const uint32_t* type, const floa
 #undef DBG_TRY
     cleanup();
     return rc;
+}
+
+int p3d_tune_schedule(p3d_scene** scenes, int32_t n, const p3d_camera* cam, const p3d_render_params* prm, const p3d_outputs* outs,
+                      int32_t frames, float* ms_per_frame, int32_t* best) {
+    if (!scenes || n <= 0 || !cam || !prm || !outs) return fail(P3D_ERR_ARG, "NULL argument");
+    for (int i = 0; i < n; i++) if (!scenes[i]) return fail(P3D_ERR_ARG, "scene is NULL");
+    if (frames <= 0) frames = 3;
+    if (best) *best = -1;
+    if (ms_per_frame) for (int k = 0; k < 6; k++) ms_per_frame[k] = -1.0f;
+    auto all = [&](int force) -> int {          // one frame on every handle, then wait for all of them
+        for (int i = 0; i < n; i++) {
+            scenes[i]->tune_force = force;
+            int rc = p3d_render(scenes[i], cam, prm, &outs[i]);
+            scenes[i]->tune_force = -1;
+            if (rc) return rc;
+        }
+        return P3D_OK;
+    };
+    auto wait = [&]() -> int { for (int i = 0; i < n; i++) { int rc = p3d_sync(scenes[i]); if (rc) return rc; } return P3D_OK; };
+    int rc = all(0);                            // also tells what there is to choose from
+    if (rc == P3D_OK) rc = wait();
+    if (rc) return rc;
+    const int NC = scenes[0]->tune_candidates;
+    if (NC == 0) return P3D_OK;                 // the schedule of this configuration is set by rule or by a flag: nothing to tune
+    const uint32_t avail = scenes[0]->tune_avail;
+    float ms[6] = {-1.0f, -1.0f, -1.0f, -1.0f, -1.0f, -1.0f};
+    int win = -1;
+    for (int c = 0; c < NC; c++) {
+        if (!(avail & (1u << c))) continue;
+        if ((rc = all(c)) != P3D_OK || (rc = wait()) != P3D_OK) return rc;                  // untimed: code objects, workspaces
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int f = 0; f < frames; f++) if ((rc = all(c)) != P3D_OK) return rc;
+        if ((rc = wait()) != P3D_OK) return rc;
+        ms[c] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() / (float)(frames * n);
+        if (win < 0 || ms[c] < ms[win]) win = c;
+    }
+    for (int i = 0; i < n; i++) scenes[i]->tune_commit = win;
+    if (scenes[0]->verbose)
+        fprintf(stderr, "p3d: tuned choice, %d handle(s) in flight (ms per frame; wavefront / tree / tile, shared walks then private): %.3f %.3f %.3f | %.3f %.3f %.3f -> %d\n",
+                n, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], win);
+    if (ms_per_frame) memcpy(ms_per_frame, ms, sizeof ms);
+    if (best) *best = win;
+    return P3D_OK;
 }
 
 int p3d_debug_powf(int device, uint32_t n, const float* x, const float* y, float* out) {
