@@ -48,13 +48,11 @@ def main():
                              "vgpr": row["VGPR_Count"], "accum_vgpr": row["Accum_VGPR_Count"], "sgpr": row["SGPR_Count"],
                              "scratch": row["Scratch_Size"]}
     # digest of the kernel sources these counters were taken from (bench.py flags a profile of other kernels as stale)
-    import hashlib
-    hd = hashlib.sha256()
-    cs_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "u_4a_2s_p3d_raytracer_template2_amd", "csrc")
-    for f in ("p3d_kernels.hip", "p3d_shade.h", "p3d_traverse.h", "p3d_device_math.h", "p3d_device_types.h", "bvh_device.hip",
-              "pt_kernels.hip"):                      # == bench.py: DEVICE_SOURCES
-        hd.update(open(os.path.join(cs_dir, f), "rb").read())
-    res = {"_note": note, "kernel_source_digest": hd.hexdigest()[:16], "kernels": {}}
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    import bench                                       # one list of kernel sources: bench.DEVICE_SOURCES
+    res = {"_note": note, "kernel_source_digest": bench.kernel_source_digest(), "kernels": {}}
     for k, cs in sorted(acc.items()):
         e = {c: v[0] / v[1] for c, v in sorted(cs.items())}
         e["_n"] = max(v[1] for v in cs.values())
