@@ -243,16 +243,8 @@ template <> struct View<false> {
         for (int a = 0; a < 3; a++) { g.qs[a] = P.q_scale[a]; g.qb[a] = P.q_base[a]; }
         return g;
     }
-    // kernels that shade: powf's tables and coefficients (the head of every blob) go to LDS address 0 (p3d_powf.h);
-    // one barrier, reached by every thread of the workgroup (call before any divergent exit)
-    static __device__ __forceinline__ GlobalScene make_shading(const LaunchParams& P) {
-        const float4* src = reinterpret_cast<const float4*>(P.blob);
-        float4* dst = reinterpret_cast<float4*>(p3d_lds);
-        if (threadIdx.x < P3D_POW_TAB_BYTES / 16u) dst[threadIdx.x] = src[threadIdx.x];
-        __syncthreads();
-        return make(P);
-    }
-    static __device__ __forceinline__ uint32_t scene_dwords(const LaunchParams&) { return P3D_POW_TAB_BYTES / 4u; }
+    static __device__ __forceinline__ GlobalScene make_shading(const LaunchParams& P) { return make(P); }
+    static __device__ __forceinline__ uint32_t scene_dwords(const LaunchParams&) { return 0; }
 };
 template <> struct View<true> {
     typedef LdsScene type;
@@ -1052,7 +1044,7 @@ __global__ void debug_intersect_kernel(uint32_t n, const uint32_t* type, const f
 }
 
 // ------------------------------------------------------------------ launchers (host)
-static size_t scene_lds_bytes(const LaunchParams& P, bool lds) { return lds ? (size_t)P.blob_quads * 16 : (size_t)P3D_POW_TAB_BYTES; }
+static size_t scene_lds_bytes(const LaunchParams& P, bool lds) { return lds ? (size_t)P.blob_quads * 16 : 0; }
 // frames of the tree kernel: private memory for scenes read from HBM up to depth 8, LDS otherwise
 static int tree_private_dwords(const LaunchParams& P, bool lds) {
     if (lds || P.accel == 1) return 0;

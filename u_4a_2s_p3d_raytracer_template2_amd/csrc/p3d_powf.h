@@ -97,6 +97,29 @@ struct PowTabLds {
         shift = p2.y; c0 = p3.x; c1 = p3.y; c2 = p4.x;
     }
 };
+
+// Kernels that read the scene from HBM read the same 592 bytes at the head of the blob through the vector memory path
+// (L1 hits after the first wave): VGPR temporaries again, no LDS -- 592 bytes of LDS per one-wave workgroup cost the 10^6-
+// primitive scene a resident wave per CU (2.16 against 1.97 ms per frame in flight).  `zero` is a VGPR holding 0 that the
+// compiler cannot see through: with a provably uniform address it would use scalar loads, i.e. SGPR pairs, again.
+struct PowTabGlobal {
+    const double2* base; uint32_t zero;
+    __device__ __forceinline__ explicit PowTabGlobal(const void* blob) : base(reinterpret_cast<const double2*>(blob)) {
+        zero = 0u; asm volatile("" : "+v"(zero));
+    }
+    __device__ __forceinline__ void log2_entry(int i, double& invc, double& logc) const { const double2 e = base[(uint32_t)i + zero]; invc = e.x; logc = e.y; }
+    __device__ __forceinline__ uint64_t exp2_entry(uint32_t j) const { return reinterpret_cast<const uint64_t*>(base)[32u + j + zero]; }
+    __device__ __forceinline__ void log2_coefs(double& a0, double& a1, double& a2, double& a3, double& a4) const {
+        const double2* c = base + 32u + zero;
+        const double2 p0 = c[0], p1 = c[1], p2 = c[2];
+        a0 = p0.x; a1 = p0.y; a2 = p1.x; a3 = p1.y; a4 = p2.x;
+    }
+    __device__ __forceinline__ void exp2_coefs(double& shift, double& c0, double& c1, double& c2) const {
+        const double2* c = base + 32u + zero;
+        const double2 p2 = c[2], p3 = c[3], p4 = c[4];
+        shift = p2.y; c0 = p3.x; c1 = p3.y; c2 = p4.x;
+    }
+};
 #endif
 
 // 0: y is not an integer, 1: odd integer, 2: even integer (decides the sign and validity of (x < 0)^y)

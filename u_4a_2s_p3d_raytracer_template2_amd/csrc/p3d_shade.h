@@ -97,8 +97,13 @@ __device__ __forceinline__ bool light_occluded(const LaunchParams& P, const SV& 
     if (WALK == WALK_GRID) return need ? grid_any<COUNT>(P, sv, sr, length, ctr) : false;   // Grid::Traverse(Ray&), RT/grid.cpp:313
     return need ? any_hit<COUNT>(P, sv, sr, bounded, length, tc.lane, ctr) : false;
 }
+// where a kernel reads powf's tables and coefficients (the head of the scene blob): the LDS copy of the scene, or the blob
+__device__ __forceinline__ PowTabLds pow_tab(const LdsScene&) { return PowTabLds(); }
+__device__ __forceinline__ PowTabGlobal pow_tab(const GlobalScene& g) { return PowTabGlobal(g.q); }
+
 // Blinn-Phong term of one unoccluded light, RT/main.cpp:512-525
-__device__ __forceinline__ void light_term(V3 L, V3 lcol, V3& color, const Mtl& M, const Ray& ray, V3 normal) {
+template <class SV>
+__device__ __forceinline__ void light_term(const SV& sv, V3 L, V3 lcol, V3& color, const Mtl& M, const Ray& ray, V3 normal) {
     L = normalized(L);        // (the same value light_occluded() formed for a bounded shadow ray: CSE'd when inlined)
     V3 H = normalized(add(L, mul(ray.d, -1.0f)));
     float VdotN = dot(H, normal);
@@ -113,7 +118,7 @@ __device__ __forceinline__ void light_term(V3 L, V3 lcol, V3& color, const Mtl& 
         return;
     }
     // the host libm's powf, bit for bit (p3d_powf.h); max2 is +0 or positive
-    V3 spec = mul(cmul(lcol, M.spec), p3d_powf_nonneg(max2, M.shine, PowTabLds()));
+    V3 spec = mul(cmul(lcol, M.spec), p3d_powf_nonneg(max2, M.shine, pow_tab(sv)));
     color = add(color, add(mul(diff, M.kd), mul(mul(spec, M.ks), 0.4f)));
 }
 
@@ -252,7 +257,7 @@ __device__ __forceinline__ NodeOut shade_hit(const LaunchParams& P, const SV& sv
                 const float4* lp = reinterpret_cast<const float4*>(P.lights + l0 + i);
                 float4 lpos = lp[0], lcol = lp[1];
                 V3 L = sub(light_position<STOCH>(P, lpos, l0 + i, rng, sample), hit_point);
-                light_term(L, mk(lcol.x, lcol.y, lcol.z), color, Ml, ray, normal);
+                light_term(sv, L, mk(lcol.x, lcol.y, lcol.z), color, Ml, ray, normal);
             }
         }
     }
