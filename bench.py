@@ -44,7 +44,10 @@ Extra objects on the JSON line:
                  fetches -- the object carries lanes active, SQ_WAIT_ANY / SQ_WAVE_CYCLES, L1 / L2 hit rates, L2 and
                  fabric GB/s against their peaks, and the same vector-issue fraction (= achieved / peak / frac).
                  Every number can be recomputed from the files named in roofline.source;
-                 roofline.kernel_ms_live is this run's own HIP-event duration of the dominant launch.
+                 roofline.kernel_ms_live is this run's own HIP-event duration of the launch named in
+                 kernel_ms_live_of (the schedule's first launch: what p3d_get_profile times).  Those figures are of ONE
+                 frame alone; roofline.whole_frame (N = 1) is the timed region as a whole: the vector instructions of
+                 all launches of a frame (same PMC files) over this run's time per frame with its frames in flight.
   "cpu_baseline" at N = 1: the REFERENCE's own object code (oracle/_ref, built from /root/reference in the build
                  container and carried as a .so) rendering whole frames of the same configuration on one host
                  core -- the reference is single-threaded; the oracle port on all cores is reported beside it.
@@ -272,7 +275,7 @@ def roofline_from_profiles(workload, live, profile_key=None):
     out = {"bound": "fetch_latency" if hbm_scene else "valu_issue", "achieved": None,
            "peak": N_SIMD * CLOCK_GHZ / VALU_CYCLES_PER_INST, "unit": "Gwave-instr/s",
            "frac": None, "frac_of": "vector-instruction issue (one wave64 VALU instruction per 2 cycles per SIMD)",
-           "traffic": None, "kernel": live.get("kernel"), "kernel_ms_live": live.get("kernel_ms"),
+           "traffic": None, "kernel": live.get("kernel"), "kernel_ms_live": live.get("kernel_ms"), "kernel_ms_live_of": live.get("kernel"),
            "frame_device_ms_live": live.get("frame_ms"),
            "algorithmic": {"bytes_per_frame": live.get("alg_bytes"), "GBps": live.get("alg_gbps"),
                            "frac_of_hbm_peak": None if live.get("alg_gbps") is None else live["alg_gbps"] / HBM_PEAK_GBS,
@@ -353,6 +356,31 @@ def roofline_from_profiles(workload, live, profile_key=None):
                           "frac_of_hbm_peak": out["traffic"] / (tk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                           "note": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch (gfx950 correction, separate passes)"
                                   + (": node / primitive fetches that miss L2 + frame buffer" if hbm_scene else ": frame buffer + ray / node queues")}
+    # the whole frame at the rate the timed region ran it: every ray kernel's vector instructions (PMC, per launch) x its
+    # launches per frame (kernel stats) over this run's time per frame with its frames in flight
+    first = {"tree": "whitted_tree_kernel", "tile": "wf_tile_kernel", "wavefront": "wf_primary_kernel"}.get(live.get("schedule"))
+    frames_in_profile = sum(float(r.get("Calls") or 0) for r in ray if first and first in r["Name"])
+    if frames_in_profile and live.get("frame_ms_in_flight"):
+        tot, missing = 0.0, False
+        for r in ray:
+            if not any(m in r["Name"] for m in mine):
+                continue
+            e = None
+            for k2, v2 in pmc.get("kernels", {}).items():
+                if _kname(k2) == _kname(r["Name"]):
+                    e = v2
+            if not (e and e.get("SQ_INSTS_VALU")):
+                missing = True
+                continue
+            tot += e["SQ_INSTS_VALU"] * float(r.get("Calls") or 0) / frames_in_profile
+        if tot and not missing:
+            ach = tot / (live["frame_ms_in_flight"] * 1e-3) / 1e9
+            out["whole_frame"] = {"valu_wave_instr_per_frame": tot, "ms_per_frame": live["frame_ms_in_flight"],
+                                  "achieved": ach, "peak": out["peak"], "unit": out["unit"], "frac": ach / out["peak"],
+                                  "note": "all launches of a frame (SQ_INSTS_VALU per launch x launches per frame, from the committed profile) over "
+                                          "this run's time per frame with %s frame(s) in flight: what the timed region as a whole makes of the "
+                                          "vector-issue roof; the per-kernel figures above are one frame alone" % live.get("frames_in_flight", "?")}
+    if tk.get("valu_issue_frac") is not None:
         if hbm_scene and tk.get("fetch"):
             out["fetch_latency"] = dict(tk["fetch"], lanes_active=tk.get("lane_utilisation"), valu_issue_frac=tk.get("valu_issue_frac"),
                                         salu_issue_frac=tk.get("salu_issue_frac"),
@@ -712,7 +740,8 @@ def main():
         total_rays = rays_frame * B * args.steps
         dominant = {"tree": "p3d::whitted_tree_kernel", "tile": "p3d::wf_tile_kernel", "wavefront": "p3d::wf_primary_kernel"}[chosen]
         live = {"kernel": dominant, "schedule": chosen, "kernel_ms": kern_ms, "frame_ms": frame_dev_ms, "alg_bytes": int(alg_bytes),
-                "alg_gbps": alg_bytes / (frame_dev_ms * 1e-3) / 1e9}
+                "alg_gbps": alg_bytes / (frame_dev_ms * 1e-3) / 1e9, "frames_in_flight": F,
+                "frame_ms_in_flight": dt_max / args.steps / B * 1e3 if world == 1 else None}
         gather_verified = None
         if world > 1:
             # the gathered, de-interleaved frame against a one-GPU render of the same frame on this rank
