@@ -79,6 +79,15 @@ def test_set_skybox_rejects_bad_arguments():
     assert b"NULL" in L.p3d_last_error()
 
 
+def test_tune_schedule_and_powf_probe_reject_bad_arguments():
+    L = P.lib()
+    best = C.c_int32(7)
+    assert L.p3d_tune_schedule(None, 1, None, None, None, 3, None, C.byref(best)) == -1      # P3D_ERR_ARG, no GPU touched
+    assert L.p3d_tune_schedule(None, 0, None, None, None, 3, None, None) == -1
+    assert L.p3d_debug_powf(0, 4, None, None, None) == -1
+    assert L.p3d_debug_powf(0, 0, (C.c_float * 1)(), (C.c_float * 1)(), (C.c_float * 1)()) == 0   # nothing to do: not an error
+
+
 def test_host_grid_of_an_empty_and_of_a_flat_scene():
     """Grid::Build's cell-count formula on no primitives is (int)NaN -- undefined behaviour in the reference; the host
     builder answers with ONE empty cell.  A scene with no extent on one axis still gets the reference's grid (every
