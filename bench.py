@@ -71,6 +71,7 @@ L2_PEAK_GBS = 34500.0            # aggregate L2 bandwidth (MI355X_MICROARCH.md, 
 CLOCK_GHZ = 2.4                  # max shader clock (MI355X_MICROARCH.md)
 N_SIMD, N_CU = 1024, 256
 VALU_CYCLES_PER_INST = 2.0       # one wave64 VALU instruction per 2 cycles per SIMD (measured, ubench)
+SALU_CYCLES_PER_INST_MIXED = 3.62   # a scalar instruction interleaved 1:2 with vector ones: (12 x 2.13 - 8 x 1.68) / 4 ticks, 1.68 ticks = 2 cycles
 ROW_BLOCK = 16
 
 WORKLOADS = {
@@ -361,7 +362,7 @@ def roofline_from_profiles(workload, live, profile_key=None):
     first = {"tree": "whitted_tree_kernel", "tile": "wf_tile_kernel", "wavefront": "wf_primary_kernel"}.get(live.get("schedule"))
     frames_in_profile = sum(float(r.get("Calls") or 0) for r in ray if first and first in r["Name"])
     if frames_in_profile and live.get("frame_ms_in_flight"):
-        tot, missing = 0.0, False
+        tot, tot_s, missing = 0.0, 0.0, False
         for r in ray:
             if not any(m in r["Name"] for m in mine):
                 continue
@@ -373,6 +374,7 @@ def roofline_from_profiles(workload, live, profile_key=None):
                 missing = True
                 continue
             tot += e["SQ_INSTS_VALU"] * float(r.get("Calls") or 0) / frames_in_profile
+            tot_s += (e.get("SQ_INSTS_SALU") or 0.0) * float(r.get("Calls") or 0) / frames_in_profile
         if tot and not missing:
             ach = tot / (live["frame_ms_in_flight"] * 1e-3) / 1e9
             out["whole_frame"] = {"valu_wave_instr_per_frame": tot, "ms_per_frame": live["frame_ms_in_flight"],
@@ -380,6 +382,16 @@ def roofline_from_profiles(workload, live, profile_key=None):
                                   "note": "all launches of a frame (SQ_INSTS_VALU per launch x launches per frame, from the committed profile) over "
                                           "this run's time per frame with %s frame(s) in flight: what the timed region as a whole makes of the "
                                           "vector-issue roof; the per-kernel figures above are one frame alone" % live.get("frames_in_flight", "?")}
+            # vector AND scalar instructions share a SIMD's issue: interleaved 2:1 in one wave they cost 2.13 ticks each where a
+            # vector instruction alone costs 1.68 (profiles/r02_valu_rate_ubench.txt, 4 waves per SIMD; 1.68 ticks = 2 cycles),
+            # i.e. 3.6 cycles per scalar instruction beside 2 per vector instruction
+            cyc = tot * VALU_CYCLES_PER_INST + tot_s * SALU_CYCLES_PER_INST_MIXED
+            floor_ms = cyc / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
+            out["whole_frame"]["issue_mix"] = {"salu_wave_instr_per_frame": tot_s, "cycles_per_valu": VALU_CYCLES_PER_INST,
+                                               "cycles_per_salu_interleaved": SALU_CYCLES_PER_INST_MIXED, "floor_ms_per_frame": floor_ms,
+                                               "frac": floor_ms / live["frame_ms_in_flight"],
+                                               "note": "this run's time per frame against the time the frame's vector + scalar instructions need at "
+                                                       "the measured interleaved issue rates: how close the timed region is to running out of issue slots"}
     if tk.get("valu_issue_frac") is not None:
         if hbm_scene and tk.get("fetch"):
             out["fetch_latency"] = dict(tk["fetch"], lanes_active=tk.get("lane_utilisation"), valu_issue_frac=tk.get("valu_issue_frac"),
