@@ -989,10 +989,12 @@ int p3d_render(p3d_scene* s, const p3d_camera* cam, const p3d_render_params* prm
         PT.tw_rays_off = 0; PT.tw_nodes_off = (uint32_t)slot_rays; PT.tw_rng_off = (uint32_t)(slot_rays + slot_nodes);
         if (measuring >= 0) HIP_TRY(hipEventRecord(s->ev_pick[0], s->stream));
         if (profile) HIP_TRY(hipEventRecord(s->ev_prof[2], s->stream));
-        // heaviest tile first (scenes read from HBM: their tiles differ by orders of magnitude; LDS scenes' do not)
+        // heaviest tile first.  Scenes read from HBM: their tiles differ by orders of magnitude.  Scenes served from LDS run
+        // this schedule for sample loops (config 4), where a glass tile is a serial chain 15 x as long as a sky tile and the
+        // natural order left the last fifth of the frame to a few workgroups: 4.77 -> 3.81 ms (profiles/r03_exp31_32_config4_tail.txt)
         bool lpt_sort = false;
         const int32_t lkey[9] = {cam->res_x, cam->res_y, prm->max_depth, prm->accel, prm->spp, rank, world, (int32_t)prm->features, SCHED_TILE};
-        if (!lds_scene && s->tile_lpt_enabled && PT.n_tiles >= 64) {
+        if (s->tile_lpt_enabled && PT.n_tiles >= 64) {
             int rc = tile_order_begin(s, s->tile_lpt, lkey, (uint32_t)PT.n_tiles, &PT.tile_order, &PT.tile_cost, &lpt_sort);
             if (rc) return rc;
         }

@@ -665,13 +665,13 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
         if (tid == 0) T->tile = atomicAdd(&P.tw_ctrl[0], 1u);
         __syncthreads();
         if ((int)T->tile >= P.n_tiles) {                         // workgroup-uniform
-            if (!LDS && P.tile_cost && tid == 0 && prev_tile >= 0) P.tile_cost[prev_tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
+            if (P.tile_cost && tid == 0 && prev_tile >= 0) P.tile_cost[prev_tile] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_tile);
             break;
         }
-        const int tile = (!LDS && P.tile_order) ? (int)P.tile_order[T->tile] : (int)T->tile;     // (heaviest first, once measured)
-        if (tid == 0 && ((!LDS && P.tile_cost) || P.dbg_stamps)) {
+        const int tile = P.tile_order ? (int)P.tile_order[T->tile] : (int)T->tile;     // (heaviest first, once measured)
+        if (tid == 0 && (P.tile_cost || P.dbg_stamps)) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (!LDS && P.tile_cost && prev_tile >= 0) P.tile_cost[prev_tile] = (uint32_t)(now - t_tile);
+            if (P.tile_cost && prev_tile >= 0) P.tile_cost[prev_tile] = (uint32_t)(now - t_tile);
             if (P.dbg_stamps) {                                  // diagnostic: one record per TILE (0 start, 1 end, 2 workgroup)
                 if (prev_tile >= 0) P.dbg_stamps[(size_t)prev_tile * 8 + 1] = now;
                 P.dbg_stamps[(size_t)tile * 8] = now;
