@@ -254,7 +254,7 @@ def load_profile(workload):
     try:
         import csv
         rows = list(csv.DictReader(open(os.path.join(REPO, "profiles", cur["kernel_stats"]))))
-        stats = [r for r in rows if "p3d::" in r.get("Name", "")]
+        stats = [r for r in rows if "p3d::" in r.get("Name", "") or "p3dpt::" in r.get("Name", "")]
     except Exception:
         pass
     try:
@@ -450,6 +450,13 @@ def bench_pathtracer(args, torch, dist, P, rank, world, local_rank, dev, comm):
                        "image_mean": float(img.mean().item())},
             "roofline": None,
         }
+        if world == 1 and spp == 256:
+            # one launch per step: the step IS the kernel (HIP-event bracket = the barrier-to-barrier time of the timed region)
+            rl = roofline_from_profiles("pathtracer", {"kernel": "p3dpt::pt_frames_kernel", "kernel_ms": dt_max / args.steps * 1e3,
+                                                       "frame_ms": dt_max / args.steps * 1e3})
+            rl["algorithmic"] = {"note": "the path tracer's scene is procedural (hashed per ray, PT/P3D_RT.glsl:88-178): there is no scene data to read; "
+                                         "HBM sees the running sums only (12 B per pixel per launch)"}
+            line["roofline"] = rl
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle_py as O
             w, h, n = 240, 135, 4

@@ -27,4 +27,4 @@ for i in $WANT; do
   echo "pass $i done: $p"
   DIRS="$DIRS $OUT/pass$i"
 done
-python3 "$R/tools/pmc_summary.py" "$OUT/summary.json" $DIRS --kernels p3d:: --note "rocprofv3 --pmc, one pass per counter group, of: ${P3D_PMC_SCRIPT:-bench.py} $*"
+python3 "$R/tools/pmc_summary.py" "$OUT/summary.json" $DIRS --kernels p3d --note "rocprofv3 --pmc, one pass per counter group, of: ${P3D_PMC_SCRIPT:-bench.py} $*"

@@ -41,6 +41,8 @@ pmc config4 tools/config4.py
 S6=$(sched_of $O/bench_synthetic_1e6.json); echo "1e6 primitives profiled as: $S6"
 kt synthetic_1000000 $R/tools/render_frames.py 1000000 $S6 30
 pmc synthetic_1000000 tools/render_frames.py 1000000 $S6 24
+kt pathtracer $R/bench.py --workload pathtracer --no-cpu-baseline --steps 2 --warmup 1
+pmc pathtracer bench.py --workload pathtracer --no-cpu-baseline --steps 1 --warmup 1
 ls -la $O | head -60
 echo done
 # frames in flight of config 2 (the default is 4)
