@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -16,6 +17,7 @@ struct Cam { f3 eye, u, v, n; float width, height, lensRadius, planeDist, focusD
 struct PtLaunch {
     Cam cam; float res_x, res_y; int32_t ires_x, ires_y; int32_t n_frames, first_frame, frame_stride;
     float time0, dt; float* rgba; float* linear;
+    int32_t n_chunks, chunk_frames; float* partial;
 };
 hipError_t launch_pt_frames(const PtLaunch& P, hipStream_t stream);
 hipError_t launch_pt_hash(uint32_t n, const uint32_t* a, const uint32_t* b, uint32_t* out, hipStream_t stream);
@@ -43,6 +45,7 @@ struct p3d_pt {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void* d_rgba = nullptr; size_t rgba_cap = 0;
     void* d_linear = nullptr; size_t linear_cap = 0;
+    void* d_partial = nullptr; size_t partial_cap = 0;      // partial linear sums of the frame runs (linear-only requests)
 };
 
 extern "C" {
@@ -67,6 +70,7 @@ int p3d_pt_destroy(p3d_pt* h) {
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); }
     if (h->d_rgba) (void)hipFree(h->d_rgba);
     if (h->d_linear) (void)hipFree(h->d_linear);
+    if (h->d_partial) (void)hipFree(h->d_partial);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -141,6 +145,19 @@ int p3d_pt_render(p3d_pt* h, const p3d_pt_params* p, const p3d_pt_outputs* o) {
             if (h->linear_cap < npx * 12) { if (h->d_linear) (void)hipFree(h->d_linear); h->d_linear = nullptr; PT_TRY(hipMalloc(&h->d_linear, npx * 12)); h->linear_cap = npx * 12; }
             L.linear = (float*)h->d_linear;
         }
+    }
+    // Linear sums only: no recurrence runs from frame to frame, so a strip's frames are cut into runs of >= 16 (at most 16
+    // runs): the launch is then no longer as long as its most expensive strip (pt_kernels.hip).  Sums are added in run order.
+    if (!L.rgba && L.linear && p->n_frames >= 32) {
+        const int chunks = std::min(16, p->n_frames / 16);
+        const size_t bytes = (size_t)chunks * npx * 12;
+        if (h->partial_cap < bytes) {
+            if (h->d_partial) (void)hipFree(h->d_partial);
+            h->d_partial = nullptr; h->partial_cap = 0;
+            PT_TRY(hipMalloc(&h->d_partial, bytes));
+            h->partial_cap = bytes;
+        }
+        L.n_chunks = chunks; L.chunk_frames = (p->n_frames + chunks - 1) / chunks; L.partial = (float*)h->d_partial;
     }
     PT_TRY(launch_pt_frames(L, h->stream));
     if (o->memory != 1) {

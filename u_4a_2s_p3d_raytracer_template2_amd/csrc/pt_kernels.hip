@@ -341,11 +341,20 @@ struct PtLaunch {
     int32_t n_frames, first_frame, frame_stride;
     float time0, dt;
     float* rgba; float* linear;
+    // linear sums only (no buffer-A recurrence to carry from frame to frame): the frames of a strip are cut into n_chunks
+    // runs of chunk_frames, one wave each, whose partial sums land in partial[chunk][pixel][3]; pt_sum_chunks_kernel adds
+    // them in chunk order.  n_chunks <= 1: one wave per strip carries all frames (needed for rgba).
+    int32_t n_chunks, chunk_frames;
+    float* partial;
 };
 
 // One wave (a 16x4 pixel strip) per workgroup: a wave keeps its pixels for all n_frames frames, so its
 // run time varies a lot from strip to strip; with four waves per workgroup the wave slots of the early
 // finishers stayed reserved until the slowest one was done.  PT_WAVES_PER_EU caps the register budget.
+// Round 3: the launch was bound by its LONGEST strips -- 256 frames of a strip full of glass are a serial chain of
+// ~200 ms while the average strip needs 10, and the profile showed 1.5 of 5 wave slots per SIMD occupied on average
+// (profiles/r03_pathtracer_pmc.json).  Callers that want the linear sums only get the frames of a strip cut into runs
+// (PtLaunch::n_chunks): 221 -> 85 ms for 1080p x 256 samples.
 #ifndef PT_WAVES_PER_EU
 #define PT_WAVES_PER_EU 5
 #endif
@@ -362,14 +371,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         sets.moving_lo = __ballot(c0 == 0); sets.moving_hi = __ballot(c1 == 0);
     }
     const int tiles_x = (P.ires_x + 15) / 16;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int n_strips = tiles_x * ((P.ires_y + 3) / 4);
+    const int strip = (int)blockIdx.x % n_strips, chunk = (int)blockIdx.x / n_strips;     // chunk-major: a strip's runs start far apart
+    const int tx = strip % tiles_x, ty = strip / tiles_x;
     const int x = tx * 16 + (threadIdx.x & 15), y = ty * 4 + (threadIdx.x >> 4);
     if (x >= P.ires_x || y >= P.ires_y) return;
     const float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;                 // gl_FragCoord
     const float pix_hash = (float)base_hash(__float_as_uint(fcx), __float_as_uint(fcy)) / (float)0xffffffffU;
     float prev0 = 0.0f, prev1 = 0.0f, prev2 = 0.0f, prevw = 0.0f;             // buffer A texel of this pixel
     f3 sum = F3(0, 0, 0);
-    for (int j = 0; j < P.n_frames; j++) {
+    const int j0 = P.n_chunks > 1 ? chunk * P.chunk_frames : 0;
+    const int j1 = P.n_chunks > 1 ? (j0 + P.chunk_frames < P.n_frames ? j0 + P.chunk_frames : P.n_frames) : P.n_frames;
+    for (int j = j0; j < j1; j++) {
         const int k = P.first_frame + j * P.frame_stride;
         const float iTime = P.time0 + (float)k * P.dt;
         float gSeed = pix_hash + iTime;                                       // PT/P3D_RT.glsl:288
@@ -395,8 +408,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         prev0 = g.x; prev1 = g.y; prev2 = g.z; prevw = w;
     }
     const size_t p = (size_t)y * P.ires_x + x;
+    if (P.n_chunks > 1) {
+        float* dst = P.partial + ((size_t)chunk * P.ires_x * P.ires_y + p) * 3;
+        dst[0] = sum.x; dst[1] = sum.y; dst[2] = sum.z;
+        return;
+    }
     if (P.rgba) reinterpret_cast<float4*>(P.rgba)[p] = make_float4(prev0, prev1, prev2, prevw);
     if (P.linear) { P.linear[3 * p] = sum.x; P.linear[3 * p + 1] = sum.y; P.linear[3 * p + 2] = sum.z; }
+}
+
+// linear[i] = partial[0][i] + partial[1][i] + ... in chunk order (the same order on every run: same bits)
+__global__ void pt_sum_chunks_kernel(const float* partial, float* linear, size_t n, int n_chunks) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = partial[i];
+    for (int c = 1; c < n_chunks; c++) s += partial[(size_t)c * n + i];
+    linear[i] = s;
 }
 
 __global__ void pt_hash_kernel(uint32_t n, const uint32_t* a, const uint32_t* b, uint32_t* out) {
@@ -406,7 +433,12 @@ __global__ void pt_hash_kernel(uint32_t n, const uint32_t* a, const uint32_t* b,
 
 hipError_t launch_pt_frames(const PtLaunch& P, hipStream_t stream) {
     const int tiles = ((P.ires_x + 15) / 16) * ((P.ires_y + 3) / 4);
-    hipLaunchKernelGGL(pt_frames_kernel, dim3(tiles), dim3(64), 0, stream, P);
+    const int chunks = P.n_chunks > 1 ? P.n_chunks : 1;
+    hipLaunchKernelGGL(pt_frames_kernel, dim3((unsigned)tiles * (unsigned)chunks), dim3(64), 0, stream, P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || chunks == 1) return e;
+    const size_t n = (size_t)P.ires_x * P.ires_y * 3;
+    hipLaunchKernelGGL(pt_sum_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P.partial, P.linear, n, chunks);
     return hipGetLastError();
 }
 hipError_t launch_pt_hash(uint32_t n, const uint32_t* a, const uint32_t* b, uint32_t* out, hipStream_t stream) {
