@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -146,10 +147,10 @@ int p3d_pt_render(p3d_pt* h, const p3d_pt_params* p, const p3d_pt_outputs* o) {
             L.linear = (float*)h->d_linear;
         }
     }
-    // Linear sums only: no recurrence runs from frame to frame, so a strip's frames are cut into runs of >= 16 (at most 16
-    // runs): the launch is then no longer as long as its most expensive strip (pt_kernels.hip).  Sums are added in run order.
+    // Linear sums only: no recurrence runs from frame to frame, so a strip's frames are cut into runs: the launch is then no longer as long as its most expensive strip (pt_kernels.hip).  Sums are added in run order.
     if (!L.rgba && L.linear && p->n_frames >= 32) {
-        const int chunks = std::min(16, p->n_frames / 16);
+        // up to 32 runs of >= 8 frames (1080p x 256 frames: 16 x 16 76.2 ms, 32 x 8 72.9, 64 x 4 71.9, 256 x 1 75.3: tools/r03/exp34.sh)
+        const int chunks = std::max(1, std::min(32, p->n_frames / 8));
         const size_t bytes = (size_t)chunks * npx * 12;
         if (h->partial_cap < bytes) {
             if (h->d_partial) (void)hipFree(h->d_partial);
