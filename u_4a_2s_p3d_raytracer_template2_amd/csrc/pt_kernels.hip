@@ -84,44 +84,47 @@ __device__ __forceinline__ Mat metal_mat(f3 spec, float rough) { Mat m; m.type =
 __device__ __forceinline__ Mat glass_mat(f3 refract, float idx, float rough) { Mat m; m.type = MT_DIALECTRIC; m.albedo = F3(1, 1, 1); m.spec = F3(0.04f, 0.04f, 0.04f); m.refIdx = idx; m.refract = refract; m.rough = rough; return m; }
 
 // ---- primitives, PT/common.glsl:334-500
+// Written without per-lane early returns (as the Whitted intersectors, p3d_device_math.h): every lane evaluates the
+// shader's expressions in the shader's order under an `ok` predicate; lanes the shader would have returned from compute
+// values nobody uses.  A divergent `if` is three scalar instructions on a kernel bound by scalar issue; each test keeps one
+// wave-level exit after its cheap rejections and one branch around the record update.  Same arithmetic, same bits.
 __device__ __forceinline__ bool hit_triangle(f3 v0, f3 v1, f3 v2, const Ray& r, float tmin, float tmax, Rec& rec) {
     const f3 e1 = v1 - v0, e2 = v2 - v0;
     const f3 pv = cross3(r.d, e2);
     const float det = dot3(pv, e1);
-    if (det > -0.0000001f && det < 0.0000001f) return false;
+    bool ok = !(det > -0.0000001f && det < 0.0000001f);
     const float inv = 1.0f / det;
     const f3 tv = r.o - v0;
     const float u = inv * dot3(tv, pv);
-    if (u < 0.0f || u > 1.0f) return false;
+    ok = ok && !(u < 0.0f || u > 1.0f);
+    if (__ballot(ok) == 0) return false;
     const f3 qv = cross3(tv, e1);
     const float v = inv * dot3(r.d, qv);
-    if (v < 0.0f || v > 1.0f) return false;          // (sic) PT/common.glsl:364
+    ok = ok && !(v < 0.0f || v > 1.0f);              // (sic) PT/common.glsl:364
     const float t = inv * dot3(e2, qv);
-    if (t < tmax && t > tmin) {
-        rec.t = t; rec.normal = norm3(cross3(e1, e2)); rec.pos = r.o + r.d * t;
-        return true;
-    }
-    return false;
+    const bool hit = ok && t < tmax && t > tmin;
+    if (hit) { rec.t = t; rec.normal = norm3(cross3(e1, e2)); rec.pos = r.o + r.d * t; }
+    return hit;
 }
-// static and moving spheres share the test once the centre is known; `exact_normal` selects
-// normalize(pos - c) (hit_sphere) or (pos - c) / radius (hit_movingSphere)
+// static and moving spheres share the test once the centre is known; `moving` selects
+// (pos - c) / radius (hit_movingSphere) instead of normalize(pos - c) (hit_sphere)
 __device__ __forceinline__ bool hit_sphere(f3 c, float radius, bool moving, const Ray& r, float tmin, float tmax, Rec& rec) {
     const f3 L = r.o - c;
     const float b = dot3(L, r.d);
     const float cc = dot3(L, L) - radius * radius;
-    if (cc > 0.0f && b > 0.0f) return false;
     const float disc = b * b - cc;
-    if (disc < 0.0f) return false;
-    const float sq = __builtin_sqrtf(disc);
-    float t = -b - sq;
-    if (t < 0.0f) t = -b + sq;
-    if (t < tmax && t > tmin) {
+    const bool ok = !(cc > 0.0f && b > 0.0f) && !(disc < 0.0f);
+    if (__ballot(ok) == 0) return false;
+    const float sq = __builtin_sqrtf(disc);          // NaN on the bypassed lanes: every comparison below is false for them
+    const float t0 = -b - sq;
+    const float t = (t0 < 0.0f) ? (-b + sq) : t0;
+    const bool hit = ok && t < tmax && t > tmin;
+    if (hit) {
         rec.t = t; rec.pos = r.o + r.d * t;
         if (radius >= 0.0f) rec.normal = moving ? ((rec.pos - c) / radius) : norm3(rec.pos - c);
         else rec.normal = norm3(c - rec.pos);
-        return true;
     }
-    return false;
+    return hit;
 }
 
 // LDS table of the 10x10 procedural spheres (PT/P3D_RT.glsl:88-178): centre, class, hash seed
@@ -222,21 +225,32 @@ __device__ __forceinline__ bool hit_world(const SmallSphere* tab, const SphereSe
     }
     near_lo &= sets.present_lo; near_hi &= sets.present_hi;
     int best = -1;
+    // Index order, as the shader walks the field: a cell inside the rectangle is tested (a moving one after its two draws),
+    // a moving sphere outside it only advances the pixel's RNG by its two draws.  There are ~28 moving spheres and a handful
+    // of near cells, so the far ones are not walked bit by bit (a dozen scalar instructions each: this kernel was bound by
+    // scalar issue) but counted -- popcount of the moving-and-far bits below the next near cell -- and their 2 x count
+    // additions run in a counted loop: the same float additions in the same order.
     for (int half = 0; half < 2; half++) {
         const uint64_t near_m = half ? near_hi : near_lo, moving_m = half ? sets.moving_hi : sets.moving_lo;
-        uint64_t todo = near_m | moving_m;
-        while (todo) {
-            const int b = __builtin_ctzll(todo);
+        const uint64_t far_moving = moving_m & ~near_m;
+        uint64_t todo = near_m, below = 0;                       // below: bits under the cells already handled
+        for (;;) {
+            const int b = todo ? __builtin_ctzll(todo) : 64;
+            const uint64_t upto = b < 64 ? ((1ull << b) - 1ull) : ~0ull;      // bits below cell b
+            int n_far = __popcll(far_moving & upto & ~below);
+            for (; n_far >= 2; n_far -= 2) { gSeed += 0.1f; gSeed += 0.1f; gSeed += 0.1f; gSeed += 0.1f; }
+            if (n_far) { gSeed += 0.1f; gSeed += 0.1f; }
+            if (b == 64) break;
             todo &= todo - 1;
+            below = upto | (1ull << b);
             const int i = half * 64 + b;
-            const bool near = (near_m >> b) & 1ull, moving = (moving_m >> b) & 1ull;     // wave-uniform
+            const bool moving = (moving_m >> b) & 1ull;          // wave-uniform
             float h = 0.0f;
             if (moving) {          // motion blur: centre interpolated towards a RANDOM centre1, drawn per call
                 gSeed += 0.1f; const float sa = gSeed;
                 gSeed += 0.1f; const float sb = gSeed;
-                if (near) h = (float)base_hash(__float_as_uint(sa), __float_as_uint(sb)) / (float)0xffffffffU;   // hash1(gSeed)
+                h = (float)base_hash(__float_as_uint(sa), __float_as_uint(sb)) / (float)0xffffffffU;   // hash1(gSeed)
             }
-            if (!near) continue;
             const SmallSphere s = tab[i];
             f3 c = F3(s.cx, s.cy, s.cz);
             if (moving) {
