@@ -355,6 +355,11 @@ int p3d_debug_intersect(int device, uint32_t n, const uint32_t* type, const floa
  * The parity tests compare it bit for bit with the box's own libm. */
 int p3d_debug_powf(int device, uint32_t n, const float* x, const float* y, float* out);
 
+/* Exhaustive check of the device's 3-instruction reciprocal (csrc/p3d_device_math.h: frcp) against the correctly rounded
+ * division 1.0f / x it replaces in normalize() and Triangle::intercepts: the bit patterns first_bits .. first_bits +
+ * count - 1 (count <= 2^32: all floats). n_bad = patterns whose results differ (NaN = NaN), first_bad = the lowest. */
+int p3d_debug_check_rcp(int device, uint32_t first_bits, uint64_t count, uint64_t* n_bad, uint32_t* first_bad);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,9 +5,9 @@ binding that tests/ and bench.py drive it through; it holds no rendering logic a
 fallback: importing `api` without a built libp3d_hip.so raises.
 """
 from .api import (PathTracer, pt_debug_hash, ACCEL_BVH, ACCEL_GRID, ACCEL_NONE, Counters, DeviceScene, HostScene, P3DError,
-                  build_native, debug_intersect, debug_powf, device_count, host_bvh, lib, local_rows, Comm, comm_unique_id,
+                  build_native, debug_intersect, debug_powf, debug_check_rcp, device_count, host_bvh, lib, local_rows, Comm, comm_unique_id,
                   gather_all, tune_schedule)
 
 __all__ = ["PathTracer", "pt_debug_hash", "ACCEL_BVH", "ACCEL_GRID", "ACCEL_NONE", "Counters", "DeviceScene", "HostScene", "P3DError",
-           "build_native", "debug_intersect", "debug_powf", "device_count", "host_bvh", "lib", "local_rows", "Comm", "comm_unique_id",
+           "build_native", "debug_intersect", "debug_powf", "debug_check_rcp", "device_count", "host_bvh", "lib", "local_rows", "Comm", "comm_unique_id",
            "gather_all", "tune_schedule"]

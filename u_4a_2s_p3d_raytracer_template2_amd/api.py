@@ -82,7 +82,7 @@ class SceneStats(C.Structure):
 C_ABI_SYMBOLS = ["p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_scene_create",
                  "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_scene_get_stats", "p3d_local_rows", "p3d_render", "p3d_sync",
                  "p3d_get_counters", "p3d_get_profile", "p3d_last_schedule", "p3d_set_tuning", "p3d_set_stream", "p3d_timer_begin", "p3d_timer_end", "p3d_deinterleave_frames",
-                 "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_powf", "p3d_tune_schedule", "p3d_debug_set_stamps", "p3d_debug_set_stamp_level",
+                 "p3d_deinterleave", "p3d_debug_intersect", "p3d_debug_powf", "p3d_debug_check_rcp", "p3d_tune_schedule", "p3d_debug_set_stamps", "p3d_debug_set_stamp_level",
                  "p3d_comm_unique_id", "p3d_comm_create", "p3d_comm_create_all", "p3d_comm_destroy", "p3d_comm_info",
                  "p3d_gather", "p3d_gather_all", "p3d_device_alloc", "p3d_device_free", "p3d_upload", "p3d_download"]
 
@@ -151,6 +151,7 @@ def lib():
     L.p3d_pt_reduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.p3d_debug_intersect.argtypes = [C.c_int, C.c_uint32] + [C.c_void_p] * 7
     L.p3d_debug_powf.argtypes = [C.c_int, C.c_uint32] + [C.c_void_p] * 3
+    L.p3d_debug_check_rcp.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
     L.p3d_tune_schedule.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     # host shim
     L.p3dh_scene_load.restype = C.c_void_p
@@ -545,6 +546,13 @@ def debug_powf(x, y, device=0):
     out = np.zeros_like(x)
     _check(lib().p3d_debug_powf(int(device), len(x), x.ctypes.data, y.ctypes.data, out.ctypes.data), "p3d_debug_powf")
     return out
+
+
+def debug_check_rcp(first_bits=0, count=1 << 32, device=0):
+    """(mismatches, first mismatching bit pattern) of the device's frcp() against 1.0f / x over `count` bit patterns."""
+    n_bad, first_bad = C.c_uint64(0), C.c_uint32(0)
+    _check(lib().p3d_debug_check_rcp(int(device), int(first_bits), int(count), C.byref(n_bad), C.byref(first_bad)), "p3d_debug_check_rcp")
+    return int(n_bad.value), int(first_bad.value)
 
 
 def save_png(path, rgb8):

@@ -45,6 +45,7 @@ hipError_t build_lbvh_device(const std::vector<BuildPrim>& prims, const BvhOptio
                              uint32_t* d_refs, BvhStats& stats, hipStream_t stream);
 hipError_t sort_tiles_by_cost(const uint32_t* cost, uint32_t* cost_sorted, uint32_t* iota, uint32_t* order, uint32_t n,
                               void* temp, size_t& temp_bytes, hipStream_t stream);
+hipError_t launch_debug_check_rcp(uint32_t first, uint64_t count, unsigned long long* n_bad, uint32_t* first_bad, hipStream_t stream);
 hipError_t launch_debug_powf(uint32_t n, const float* x, const float* y, float* out, hipStream_t stream);
 hipError_t launch_debug_intersect(uint32_t n, const uint32_t* type, const float* prim12, const float* origin,
                                   const float* dir, int32_t* hit, float* t, float* normal, hipStream_t stream);
@@ -1286,6 +1287,28 @@ int p3d_tune_schedule(p3d_scene** scenes, int32_t n, const p3d_camera* cam, cons
                 n, ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], win);
     if (ms_per_frame) memcpy(ms_per_frame, ms, sizeof ms);
     if (best) *best = win;
+    return P3D_OK;
+}
+
+int p3d_debug_check_rcp(int device, uint32_t first_bits, uint64_t count, uint64_t* n_bad, uint32_t* first_bad) {
+    if (!n_bad || !first_bad) return fail(P3D_ERR_ARG, "NULL argument");
+    *n_bad = 0; *first_bad = 0xFFFFFFFFu;
+    if (count == 0) return P3D_OK;
+    if (count > (1ull << 32)) return fail(P3D_ERR_ARG, "count exceeds the 2^32 bit patterns");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(P3D_ERR_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long* d = nullptr;                      // [0] mismatches, [1] (low word) first mismatching pattern
+    HIP_TRY(hipMalloc((void**)&d, 16));
+    const unsigned long long init[2] = {0ull, 0xFFFFFFFFull};
+    hipError_t e = hipMemcpy(d, init, 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_debug_check_rcp(first_bits, count, d, (uint32_t*)(d + 1), nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned long long out[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(out, d, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(P3D_ERR_HIP, std::string("p3d_debug_check_rcp: ") + hipGetErrorString(e));
+    *n_bad = out[0]; *first_bad = (uint32_t)out[1];
     return P3D_OK;
 }
 

@@ -19,6 +19,21 @@ struct V3 { float x, y, z; };
 // square root in this ROCm's headers.
 __device__ __forceinline__ float fdiv(float a, float b) { return a / b; }
 __device__ __forceinline__ float fsqrt(float a) { return __builtin_sqrtf(a); }
+// 1.0f / x, correctly rounded, in 3 instructions where the compiler's division takes 11: the hardware reciprocal (1 ulp)
+// and one Newton step in FMA arithmetic, r = r0 + r0 * (1 - x * r0).  Equal to 1.0f / x for EVERY float whose exponent
+// keeps x and 1 / x normal -- checked over all 2^32 bit patterns on the device (p3d_debug_check_rcp,
+// tests/test_gpu_exact_math.py); zeros, subnormals, infinities, NaNs and |x| >= 2^126 take the division itself behind a
+// wave-level branch.  Triangle::intercepts divides 1.0 by det (via double: the same correctly rounded value) in every test.
+__device__ __forceinline__ float frcp(float x) {
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r0, 1.0f);
+    float r = __builtin_fmaf(e, r0, r0);
+    const bool plain = ((__float_as_uint(x) & 0x7f800000u) - 0x00800000u) < 0x7e000000u;     // 2^-126 <= |x| < 2^126
+    if (__ballot(!plain) != 0) {
+        if (!plain) r = 1.0f / x;
+    }
+    return r;
+}
 
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -53,12 +68,16 @@ struct Ray { V3 o, d; };
 // exit -- no active lane can still hit -- taken after its cheapest rejection.  Same arithmetic, same bits.
 
 // Triangle::intercepts, RT/scene.cpp:55-88 (e1, e2 are the stored P1-P0, P2-P0)
+// FAST_RCP: 1 / det by frcp() -- the kernels that read the scene from HBM, where the eight vector instructions saved per
+// test count (config 3: +3.5 %) and the guard's three scalar ones do not; scenes served from LDS are bound by scalar issue
+// and keep the division (with frcp there: config 2 -4.5 %, config 4 -4.5 %; tools/r03/exp36.sh).  Same bits either way.
+template <bool FAST_RCP = false>
 __device__ __forceinline__ bool hit_triangle(const Ray& r, V3 p0, V3 e1, V3 e2, float& t) {
     const V3 h = cross(r.d, e2);
     const float det = dot(e1, h);
     bool ok = !(det > -P3D_EPS && det < P3D_EPS);
     if (__ballot(ok) == 0) return false;
-    const float f = fdiv(1.0f, det);
+    const float f = FAST_RCP ? frcp(det) : fdiv(1.0f, det);
     const V3 s = sub(r.o, p0);
     const float u = f * dot(s, h);
     ok = ok & !(u < 0.0f || u > 1.0f);

@@ -1243,6 +1243,21 @@ hipError_t launch_deinterleave(const void* gathered, void* frames, int res_x, in
     return hipGetLastError();
 }
 
+// every bit pattern in [first, first + count): frcp(x) against the division it replaces (NaNs compare equal to NaNs)
+__global__ void debug_check_rcp_kernel(uint32_t first, uint64_t count, unsigned long long* n_bad, uint32_t* first_bad) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t bits = first + (uint32_t)i;
+        const float x = __uint_as_float(bits);
+        const float a = frcp(x), b = 1.0f / x;
+        const bool same = __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
+        if (!same) { atomicAdd(n_bad, 1ull); atomicMin(first_bad, bits); }
+    }
+}
+hipError_t launch_debug_check_rcp(uint32_t first, uint64_t count, unsigned long long* n_bad, uint32_t* first_bad, hipStream_t stream) {
+    hipLaunchKernelGGL(debug_check_rcp_kernel, dim3(256 * 16), dim3(256), 0, stream, first, count, n_bad, first_bad);
+    return hipGetLastError();
+}
+
 __global__ void debug_powf_kernel(uint32_t n, const float* x, const float* y, float* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = p3d_powf(x[i], y[i]);

@@ -52,6 +52,9 @@ struct LdsScene {
         return reinterpret_cast<const uint2*>(p3d_lds)[quad * 2 + pair];
     }
 };
+// which triangle test a scene kind uses (p3d_device_math.h: hit_triangle<FAST_RCP>)
+template <class SV> struct FastRcp { static constexpr bool value = false; };
+template <> struct FastRcp<GlobalScene> { static constexpr bool value = true; };
 // a leaf = three typed ranges into the primitive arrays, which the host stores in LEAF ORDER (LeafRec):
 // x = first triangle, y = first sphere, z = first box, w = counts (triangles | spheres << 8 | boxes << 16).
 // `code` = a negative child reference (p3d_device_types.h: kLeaf*).  In scenes read from HBM a leaf that is one run of
@@ -271,7 +274,7 @@ __device__ __forceinline__ void leaf_closest(const LaunchParams& P, const SV& sv
         sv_tri(sv, L.x + i, a, b, c);
         if (COUNT) ctr.tri++;
         float t;
-        const bool h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
+        const bool h = hit_triangle<FastRcp<SV>::value>(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
         take_closer(best, h, t, (1u << kRefKindShift) | (L.x + i), __float_as_uint(a.w), __float_as_uint(b.w));
     }
     _Pragma("clang loop vectorize(disable) unroll(disable)")
@@ -381,7 +384,7 @@ __device__ __forceinline__ bool leaf_any(const LaunchParams& P, const SV& sv, co
         sv_tri(sv, L.x + i, a, b, c);
         if (COUNT) ctr.tri++;
         float t;
-        const bool h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
+        const bool h = hit_triangle<FastRcp<SV>::value>(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
         occluded = occluded | (h && (!bounded || t < tmax));
     }
     _Pragma("clang loop vectorize(disable) unroll(disable)")
@@ -726,7 +729,7 @@ __device__ __forceinline__ bool prim_test(const LaunchParams& P, const SV& sv, c
         sv_tri(sv, idx, a, b, c);
         if (COUNT) ctr.tri++;
         sid = __float_as_uint(a.w); mat = __float_as_uint(b.w);
-        return hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
+        return hit_triangle<FastRcp<SV>::value>(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
     } else if (kind == 0u) {
         const float4 s = sv_sphere(sv, idx);
         const PrimMeta m = sv_sphere_meta(sv, idx);
@@ -876,7 +879,7 @@ __device__ __forceinline__ void leaf_closest_packet(const LaunchParams& P, const
         if (live) {
             if (COUNT) ctr.tri++;
             float t;
-            const bool h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
+            const bool h = hit_triangle<true>(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t);
             take_closer(best, h, t, (1u << kRefKindShift) | (tri0 + i), __float_as_uint(a.w), __float_as_uint(b.w));
         }
     }
@@ -997,7 +1000,7 @@ __device__ __forceinline__ bool any_hit_packet(const LaunchParams& P, const SV& 
                 if (hl && !occ) {
                     if (COUNT) ctr.tri++;
                     float t;
-                    const bool h = hit_triangle(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(cc.x, cc.y, cc.z), t);
+                    const bool h = hit_triangle<true>(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(cc.x, cc.y, cc.z), t);
                     occ = occ | (h && (!bounded || t < tmax));
                 }
             }
