@@ -62,7 +62,9 @@ __device__ __forceinline__ f2 random_in_unit_disk(float& seed) {                
     const f2 h = hash2(seed);
     const float phi = h.y * 6.28318530718f;
     const float r = __builtin_sqrtf(h.x * 1.0f);
-    f2 o; o.x = r * sinf(phi); o.y = r * cosf(phi);
+    float sn, cs;
+    sincosf(phi, &sn, &cs);                      // one argument reduction for both (the same values as sinf / cosf)
+    f2 o; o.x = r * sn; o.y = r * cs;
     return o;
 }
 __device__ __forceinline__ f3 random_in_unit_sphere(float& seed) {                // :78-84
@@ -70,7 +72,9 @@ __device__ __forceinline__ f3 random_in_unit_sphere(float& seed) {              
     const float phi = h.y;
     const float r = powf(h.z, 1.0f / 3.0f);
     const float s = __builtin_sqrtf(1.0f - h.x * h.x);
-    return F3(r * (s * sinf(phi)), r * (s * cosf(phi)), r * h.x);
+    float sn, cs;
+    sincosf(phi, &sn, &cs);
+    return F3(r * (s * sn), r * (s * cs), r * h.x);
 }
 
 struct Ray { f3 o, d; float t; };
@@ -414,12 +418,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER
         r.t = time;
         f3 color = ray_color(tab, sets, wave_union, gSeed, r);
         sum = sum + color;
-        // accumulation, PT/P3D_RT.glsl:345-365
-        const f3 prevLinear = pow3(F3(prev0, prev1, prev2), 2.2f);
-        const float w = prevw + 1.0f;
-        color = mix3(prevLinear, color, 1.0f / w);
-        const f3 g = pow3(color, 1.0f / 2.2f);
-        prev0 = g.x; prev1 = g.y; prev2 = g.z; prevw = w;
+        // accumulation, PT/P3D_RT.glsl:345-365 -- only when the caller wants buffer A (six powf per frame and pixel that a
+        // request for the linear sums never reads)
+        if (P.rgba) {
+            const f3 prevLinear = pow3(F3(prev0, prev1, prev2), 2.2f);
+            const float w = prevw + 1.0f;
+            color = mix3(prevLinear, color, 1.0f / w);
+            const f3 g = pow3(color, 1.0f / 2.2f);
+            prev0 = g.x; prev1 = g.y; prev2 = g.z; prevw = w;
+        }
     }
     const size_t p = (size_t)y * P.ires_x + x;
     if (P.n_chunks > 1) {
