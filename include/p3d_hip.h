@@ -330,7 +330,8 @@ int p3d_device_free(p3d_scene* scene, void* ptr);
 int p3d_upload(p3d_scene* scene, void* device_dst, const void* host_src, uint64_t bytes);
 int p3d_download(p3d_scene* scene, void* host_dst, const void* device_src, uint64_t bytes);
 
-/* Diagnostic: with a device buffer of (tiles x waves-per-workgroup x 8) uint64 set here, the
+/* (Diagnostic build only -- make -C csrc stamps, libp3d_hip_stamps.so: the product library compiles the hooks out and
+ * answers P3D_ERR_STATE to a non-NULL buffer.) With a device buffer of (tiles x waves-per-workgroup x 8) uint64 set here, the
  * level-1 kernel writes per-wave 100 MHz timestamps (tile start, after ray generation, after the
  * closest hit, after shading, after the queue append; slot 7 = hardware id). NULL turns it off
  * (default). Never changes results. tools/stamps.py turns them into a per-stage timeline. */

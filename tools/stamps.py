@@ -2,6 +2,12 @@
 """Per-wave timeline of the fused level-1 kernel (diagnostic)."""
 import os, sys
 import numpy as np
+# stamps exist only in the diagnostic build (make -C u_4a_2s_p3d_raytracer_template2_amd/csrc stamps)
+_stamps = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "u_4a_2s_p3d_raytracer_template2_amd", "libp3d_hip_stamps.so")
+if "P3D_LIB" not in os.environ:
+    if not os.path.exists(_stamps):
+        raise SystemExit("the timeline needs %s: run `make -C u_4a_2s_p3d_raytracer_template2_amd/csrc stamps`" % _stamps)
+    os.environ["P3D_LIB"] = _stamps
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 from conftest import scene_path

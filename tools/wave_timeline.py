@@ -15,11 +15,11 @@ import sys
 
 import numpy as np
 
-# level >= 2 needs the diagnostic build (make -C u_4a_2s_p3d_raytracer_template2_amd/csrc stamps)
+# stamps exist only in the diagnostic build (make -C u_4a_2s_p3d_raytracer_template2_amd/csrc stamps)
 _stamps = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "u_4a_2s_p3d_raytracer_template2_amd", "libp3d_hip_stamps.so")
-if len(sys.argv) > 3 and int(sys.argv[3]) >= 2 and "P3D_LIB" not in os.environ:
+if "P3D_LIB" not in os.environ:
     if not os.path.exists(_stamps):
-        raise SystemExit("the level-%s timeline needs %s: run `make -C u_4a_2s_p3d_raytracer_template2_amd/csrc stamps`" % (sys.argv[3], _stamps))
+        raise SystemExit("the timeline needs %s: run `make -C u_4a_2s_p3d_raytracer_template2_amd/csrc stamps`" % _stamps)
     os.environ["P3D_LIB"] = _stamps
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

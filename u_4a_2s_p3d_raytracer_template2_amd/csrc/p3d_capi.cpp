@@ -45,6 +45,7 @@ hipError_t build_lbvh_device(const std::vector<BuildPrim>& prims, const BvhOptio
                              uint32_t* d_refs, BvhStats& stats, hipStream_t stream);
 hipError_t sort_tiles_by_cost(const uint32_t* cost, uint32_t* cost_sorted, uint32_t* iota, uint32_t* order, uint32_t n,
                               void* temp, size_t& temp_bytes, hipStream_t stream);
+bool kernels_have_stamps();
 hipError_t launch_debug_check_rcp(uint32_t first, uint64_t count, unsigned long long* n_bad, uint32_t* first_bad, hipStream_t stream);
 hipError_t launch_debug_powf(uint32_t n, const float* x, const float* y, float* out, hipStream_t stream);
 hipError_t launch_debug_intersect(uint32_t n, const uint32_t* type, const float* prim12, const float* origin,
@@ -1117,6 +1118,8 @@ int p3d_get_counters(p3d_scene* s, p3d_counters* out) {
 
 int p3d_debug_set_stamps(p3d_scene* s, void* device_buffer) {
     if (!s) return fail(P3D_ERR_ARG, "scene is NULL");
+    if (device_buffer && !kernels_have_stamps())
+        return fail(P3D_ERR_STATE, "this build has no stamp hooks: use the diagnostic build (make -C csrc stamps, libp3d_hip_stamps.so)");
     s->dbg_stamps = (unsigned long long*)device_buffer;
     return P3D_OK;
 }

@@ -305,8 +305,16 @@ __device__ __forceinline__ void stamp_record(unsigned long long* r, int k) {
     if (k == 0) r[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
                        ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
 }
+// ALL stamp hooks exist only in builds with -DP3D_STAMPS (`make stamps`, libp3d_hip_stamps.so; the timeline tools select it):
+// each hook is a scalar compare and branch per wave on kernels that are bound by scalar issue (the level-1 kernel of
+// config 2: 5 hooks = 20 of its 290 scalar instructions per wave).
+#ifdef P3D_STAMPS
+constexpr bool kStamps = true;
+#else
+constexpr bool kStamps = false;
+#endif
 __device__ __forceinline__ void stamp(const LaunchParams& P, int tile, int k) {
-    if (P.dbg_stamps && P.dbg_stamp_level <= 1 && (threadIdx.x & 63) == 0)
+    if (kStamps && P.dbg_stamps && P.dbg_stamp_level <= 1 && (threadIdx.x & 63) == 0)
         stamp_record(P.dbg_stamps + ((size_t)tile * P.wg_waves + (threadIdx.x >> 6)) * 8, k);
 }
 // the same for the deeper-level kernel (p3d_debug_set_stamp_level(l), l >= 2): one record per WAVE of the launch, written
@@ -669,10 +677,10 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
             break;
         }
         const int tile = P.tile_order ? (int)P.tile_order[T->tile] : (int)T->tile;     // (heaviest first, once measured)
-        if (tid == 0 && (P.tile_cost || P.dbg_stamps)) {
+        if (tid == 0 && (P.tile_cost || (kStamps && P.dbg_stamps))) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             if (P.tile_cost && prev_tile >= 0) P.tile_cost[prev_tile] = (uint32_t)(now - t_tile);
-            if (P.dbg_stamps) {                                  // diagnostic: one record per TILE (0 start, 1 end, 2 workgroup)
+            if (kStamps && P.dbg_stamps) {                       // diagnostic: one record per TILE (0 start, 1 end, 2 workgroup)
                 if (prev_tile >= 0) P.dbg_stamps[(size_t)prev_tile * 8 + 1] = now;
                 P.dbg_stamps[(size_t)tile * 8] = now;
                 P.dbg_stamps[(size_t)tile * 8 + 2] = blockIdx.x;
@@ -747,7 +755,7 @@ __global__ __launch_bounds__(256) P3D_OCC(OCC) void wf_tile_kernel(const LaunchP
         }
         my_pixels += inside ? 1u : 0u;
     }
-    if (P.dbg_stamps && tid == 0 && prev_tile >= 0) P.dbg_stamps[(size_t)prev_tile * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (kStamps && P.dbg_stamps && tid == 0 && prev_tile >= 0) P.dbg_stamps[(size_t)prev_tile * 8 + 1] = __builtin_amdgcn_s_memrealtime();
     flush_counters<COUNT>(P, ctr, my_pixels);
     // the last workgroup out re-arms the tile counter for the next launch on this workspace (the frame
     // is self-contained on the device: safe to capture into a HIP graph and replay)
@@ -1253,6 +1261,7 @@ __global__ void debug_check_rcp_kernel(uint32_t first, uint64_t count, unsigned 
         if (!same) { atomicAdd(n_bad, 1ull); atomicMin(first_bad, bits); }
     }
 }
+bool kernels_have_stamps() { return kStamps; }
 hipError_t launch_debug_check_rcp(uint32_t first, uint64_t count, unsigned long long* n_bad, uint32_t* first_bad, hipStream_t stream) {
     hipLaunchKernelGGL(debug_check_rcp_kernel, dim3(256 * 16), dim3(256), 0, stream, first, count, n_bad, first_bad);
     return hipGetLastError();
